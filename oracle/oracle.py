@@ -1,0 +1,207 @@
+"""ctypes wrapper around oracle/libtcoracle.so (the CPU restatement).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libtcoracle.so")
+
+NGBMAX = 2360
+DESNNGB = 295
+MAXLOG = 66
+
+
+class OrcHalo(C.Structure):
+    _fields_ = [("mass_gas", C.c_double), ("d_com", C.c_double * 3), ("rho0", C.c_double),
+                ("beta", C.c_double), ("rcore", C.c_double), ("rcut", C.c_double),
+                ("have_cuspy", C.c_int), ("pad_", C.c_int)]
+
+
+class OrcIterLog(C.Structure):
+    _fields_ = [("it", C.c_int), ("err_max", C.c_double), ("err_mean", C.c_double),
+                ("err_diff", C.c_double), ("step", C.c_double)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "tc_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libtcoracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        vp, ci, cd, cf = C.c_void_p, C.c_int, C.c_double, C.c_float
+        L.orc_create.restype = vp
+        L.orc_create.argtypes = [ci, cd, cd, cd, ci, C.POINTER(OrcHalo), ci]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_set_particles.argtypes = [vp, vp, vp, vp]
+        L.orc_get_particles.argtypes = [vp] + [vp] * 6
+        L.orc_set_apot.argtypes = [vp, vp]
+        L.orc_get_apot.argtypes = [vp, vp]
+        L.orc_get_bfld.argtypes = [vp, vp]
+        L.orc_peano_key.argtypes = [cd, cd, cd, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_reversed_peano_key.argtypes = [cd, cd, cd, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_sort_by_peano_key.argtypes = [vp, vp, vp, vp]
+        L.orc_build_tree.argtypes = [vp]
+        L.orc_build_tree.restype = ci
+        L.orc_tree_nodes.argtypes = [vp] + [vp] * 6
+        L.orc_tree_nodes.restype = ci
+        L.orc_find_ngb_tree.argtypes = [vp, ci, cf, vp]
+        L.orc_find_ngb_tree.restype = ci
+        L.orc_find_ngb_simple.argtypes = [vp, ci, cf, vp]
+        L.orc_find_ngb_simple.restype = ci
+        L.orc_guess_hsml.argtypes = [vp, ci]
+        L.orc_guess_hsml.restype = cf
+        L.orc_find_sph_quantities.argtypes = [vp]
+        L.orc_find_sph_quantities.restype = ci
+        L.orc_global_density_model.argtypes = [vp, vp]
+        L.orc_regularise.argtypes = [vp, C.POINTER(OrcIterLog), ci]
+        L.orc_regularise.restype = ci
+        L.orc_wvt_step.argtypes = [vp, cd, vp, vp, ci]
+        L.orc_bfld_from_rotA.argtypes = [vp]
+        L.orc_last_stats.argtypes = [vp, C.POINTER(cd), C.POINTER(cd), C.POINTER(cd)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def peano_key(x, y, z):
+    hi, lo = C.c_uint64(), C.c_uint64()
+    lib().orc_peano_key(x, y, z, C.byref(hi), C.byref(lo))
+    return (hi.value << 64) | lo.value
+
+
+def reversed_peano_key(x, y, z):
+    hi, lo = C.c_uint64(), C.c_uint64()
+    lib().orc_reversed_peano_key(x, y, z, C.byref(hi), C.byref(lo))
+    return (hi.value << 64) | lo.value
+
+
+class Oracle:
+    """State handle mirroring the reference's globals P / SphP / Param / Halo for the gas particles."""
+
+    def __init__(self, model, pos, ids=None, hsml=None, nthreads=0):
+        """model: any object with boxsize, mpart_gas, mtotal and halos (list of dicts/objs with
+        mass_gas, d_com, rho0, beta, rcore, rcut, have_cuspy)."""
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        self.n = pos.shape[0]
+        halos = (OrcHalo * len(model.halos))()
+        for k, h in enumerate(model.halos):
+            g = (lambda name: h[name]) if isinstance(h, dict) else (lambda name: getattr(h, name))
+            halos[k].mass_gas = g("mass_gas")
+            for c in range(3):
+                halos[k].d_com[c] = g("d_com")[c]
+            halos[k].rho0, halos[k].beta = g("rho0"), g("beta")
+            halos[k].rcore, halos[k].rcut = g("rcore"), g("rcut")
+            halos[k].have_cuspy = int(g("have_cuspy"))
+        self._h = lib().orc_create(self.n, model.boxsize, model.mpart_gas, model.mtotal,
+                                   len(model.halos), halos, nthreads)
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
+        hsml = None if hsml is None else np.ascontiguousarray(hsml, dtype=np.float32)
+        lib().orc_set_particles(self._h, _p(pos), _p(ids), _p(hsml))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def particles(self):
+        n = self.n
+        out = dict(pos=np.empty((n, 3), np.float32), id=np.empty(n, np.int32), hsml=np.empty(n, np.float32),
+                   rho=np.empty(n, np.float32), varhsmlfac=np.empty(n, np.float32),
+                   rho_model=np.empty(n, np.float32))
+        lib().orc_get_particles(self._h, _p(out["pos"]), _p(out["id"]), _p(out["hsml"]), _p(out["rho"]),
+                                _p(out["varhsmlfac"]), _p(out["rho_model"]))
+        return out
+
+    def sort_by_peano_key(self):
+        n = self.n
+        hi, lo, perm = np.empty(n, np.uint64), np.empty(n, np.uint64), np.empty(n, np.int64)
+        lib().orc_sort_by_peano_key(self._h, _p(hi), _p(lo), _p(perm))
+        return hi, lo, perm
+
+    def build_tree(self):
+        return lib().orc_build_tree(self._h)
+
+    def tree_nodes(self):
+        nn = lib().orc_tree_nodes(self._h, None, None, None, None, None, None)
+        out = dict(bitfield=np.empty(nn, np.uint32), dnext=np.empty(nn, np.int32), pos=np.empty((nn, 3), np.float32),
+                   npart=np.empty(nn, np.int32), size=np.empty(nn, np.float32),
+                   tree_parent=np.empty(self.n, np.int32))
+        lib().orc_tree_nodes(self._h, _p(out["bitfield"]), _p(out["dnext"]), _p(out["pos"]), _p(out["npart"]),
+                             _p(out["size"]), _p(out["tree_parent"]))
+        return out
+
+    def find_ngb_tree(self, ipart, hsml):
+        buf = np.empty(NGBMAX, np.int32)
+        c = lib().orc_find_ngb_tree(self._h, int(ipart), float(np.float32(hsml)), _p(buf))
+        return buf[:c].copy()
+
+    def find_ngb_simple(self, ipart, hsml):
+        buf = np.empty(NGBMAX, np.int32)
+        c = lib().orc_find_ngb_simple(self._h, int(ipart), float(np.float32(hsml)), _p(buf))
+        return buf[:c].copy()
+
+    def guess_hsml(self, ipart):
+        return np.float32(lib().orc_guess_hsml(self._h, int(ipart)))
+
+    def find_sph_quantities(self):
+        rc = lib().orc_find_sph_quantities(self._h)
+        if rc < 0:
+            raise RuntimeError("oracle find_sph_quantities failed rc=%d" % rc)
+
+    def last_stats(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        lib().orc_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(queries=a.value, solver_iters=b.value, pair_evals=c.value)
+
+    def global_density_model(self):
+        out = np.empty(self.n, np.float32)
+        lib().orc_global_density_model(self._h, _p(out))
+        return out
+
+    def regularise(self, max_iter=-1):
+        log = (OrcIterLog * MAXLOG)()
+        nlog = lib().orc_regularise(self._h, log, max_iter)
+        if nlog < 0:
+            raise RuntimeError("oracle regularise failed")
+        return [dict(it=l.it, err_max=l.err_max, err_mean=l.err_mean, err_diff=l.err_diff, step=l.step)
+                for l in log[:min(nlog, MAXLOG)]]
+
+    def wvt_step(self, step, move=True):
+        hs = np.empty(self.n, np.float32)
+        de = np.empty((self.n, 3), np.float32)
+        lib().orc_wvt_step(self._h, float(step), _p(hs), _p(de), int(bool(move)))
+        return hs, de
+
+    def set_apot(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)
+        lib().orc_set_apot(self._h, _p(a))
+
+    def bfld_from_rotA(self):
+        lib().orc_bfld_from_rotA(self._h)
+        b = np.empty((self.n, 3), np.float32)
+        lib().orc_get_bfld(self._h, _p(b))
+        return b
+
+
+def format_log_line(l):
+    """The reference's per-iteration line, wvt_relax.c:91-92."""
+    return "   #%02d: Err max=%3g mean=%03g diff=%03g step=%g" % (
+        l["it"], l["err_max"], l["err_mean"], l["err_diff"], l["step"])

@@ -1,0 +1,101 @@
+/*
+ * tc_oracle.h -- CPU restatement of Toycluster's SPH-density / WVT-relaxation path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (toycluster_amd/, include/,
+ * the HIP library, the C host) may include, link, or call this.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as a checker
+ * or as the timed CPU baseline -- never as the thing shipped.
+ *
+ * PARITY STATUS: the reference path cannot be compiled in this image
+ * (src/globals.h:21-24 includes <gsl/...>, libgsl is absent, and stand-ins are
+ * not permitted), and the reference ships no tests or golden vectors.  The
+ * oracle is therefore pinned ONLY by the Peano-key known answers recorded in
+ * SURVEY.md section 8c (tests/golden/peano_kat.json).  Everything else is
+ * "parity unpinned": a line-by-line arithmetic restatement, each function
+ * citing the reference file:line it follows.
+ *
+ * Third-party algorithm restated: GSL gsl_heapsort_index (sort/sortind.c of
+ * GNU GSL, version unpinned by the reference Makefile:84), called from
+ * reference src/sort.c:192.
+ */
+#ifndef TC_ORACLE_H
+#define TC_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#define ORC_DESNNGB 295          /* globals.h:48 */
+#define ORC_NNGBDEV 0.05         /* globals.h:49 */
+#define ORC_NGBMAX (ORC_DESNNGB * 8)   /* globals.h:50 */
+#define ORC_NUMITER 64           /* wvt_relax.c:7 */
+#define ORC_ERRDIFF_LIMIT 0.01   /* wvt_relax.c:8 */
+#define ORC_MAXLOG (ORC_NUMITER + 2)
+
+typedef struct {
+    double mass_gas;     /* Halo[i].Mass[0]; 0 => skipped (wvt_relax.c:237) */
+    double d_com[3];     /* Halo[i].D_CoM */
+    double rho0;         /* Halo[i].Rho0 */
+    double beta;         /* Halo[i].Beta */
+    double rcore;        /* Halo[i].Rcore */
+    double rcut;         /* Halo[i].Rcut */
+    int    have_cuspy;   /* Halo[i].Have_Cuspy (unused without DOUBLE_BETA_COOL_CORES) */
+    int    pad_;
+} orc_halo;
+
+typedef struct {
+    int    it;
+    double err_max, err_mean, err_diff, step;
+} orc_iterlog;
+
+typedef struct orc_state orc_state;
+
+/* life cycle */
+orc_state *orc_create(int npart, double boxsize, double mpart_gas, double mtotal,
+                      int nhalos, const orc_halo *halos, int nthreads);
+void orc_destroy(orc_state *s);
+
+/* particle state (gas only).  pos is xyz-interleaved f32[3n] in [0,box]. */
+void orc_set_particles(orc_state *s, const float *pos, const int32_t *id, const float *hsml);
+void orc_get_particles(const orc_state *s, float *pos, int32_t *id, float *hsml, float *rho,
+                       float *varhsmlfac, float *rho_model);
+void orc_set_apot(orc_state *s, const float *apot3);
+void orc_get_bfld(const orc_state *s, float *bfld3);
+void orc_get_apot(const orc_state *s, float *apot3);
+
+/* peano.c:128-203, 211-284 : keys as (hi,lo) 64-bit halves of the 128-bit key */
+void orc_peano_key(double x, double y, double z, uint64_t *hi, uint64_t *lo);
+void orc_reversed_peano_key(double x, double y, double z, uint64_t *hi, uint64_t *lo);
+
+/* peano.c:46-126 : key, index heapsort, permutation of all per-particle arrays.
+ * Optional outputs (may be NULL): sorted keys (hi,lo)[n], permutation perm[n]
+ * (new index i holds old particle perm[i]). */
+void orc_sort_by_peano_key(orc_state *s, uint64_t *key_hi, uint64_t *key_lo, int64_t *perm);
+
+/* tree.c:124-271.  Requires sorted particles. */
+int  orc_build_tree(orc_state *s);     /* returns NNodes, <0 on overflow */
+int  orc_tree_nodes(const orc_state *s, uint32_t *bitfield, int32_t *dnext, float *pos3,
+                    int32_t *npart, float *size, int32_t *tree_parent);
+/* tree.c:25-111 */
+int  orc_find_ngb_tree(const orc_state *s, int ipart, float hsml, int32_t *ngblist);
+/* wvt_relax.c:296-340 */
+int  orc_find_ngb_simple(const orc_state *s, int ipart, float hsml, int32_t *ngblist);
+/* tree.c:113-121 */
+float orc_guess_hsml(const orc_state *s, int ipart);
+
+/* sph.c:13-75 (includes sort + tree build).  Returns 0, or <0 on failure. */
+int  orc_find_sph_quantities(orc_state *s);
+/* wvt_relax.c:227-256 for every particle */
+void orc_global_density_model(const orc_state *s, float *rho_model_out);
+/* wvt_relax.c:25-225.  max_iter<0 => reference behaviour (NUMITER).  Returns number of log lines. */
+int  orc_regularise(orc_state *s, orc_iterlog *log, int max_iter);
+/* one WVT sweep body only (wvt_relax.c:106-214) at the given step, for unit parity;
+ * writes hsml_wvt[n] and delta[3n] (xyz interleaved) if non-NULL. Does NOT call the density pass. */
+void orc_wvt_step(orc_state *s, double step, float *hsml_wvt, float *delta3, int move);
+/* sph.c:216-300 */
+void orc_bfld_from_rotA(orc_state *s);
+
+/* stats of the last orc_find_sph_quantities call */
+void orc_last_stats(const orc_state *s, double *queries_per_part, double *solver_iters_per_part,
+                    double *pair_evals_per_part);
+
+#endif
