@@ -1,0 +1,53 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol include/tcgpu.h
+declares.  No compute calls here (there is no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from toycluster_amd import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "tcgpu.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tcgpu_[a-zA-Z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(binding.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = ctypes.CDLL(binding.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), "libtcgpu.so does not export %s" % s
+    assert sorted(binding.EXPORTS) == syms, set(binding.EXPORTS) ^ set(syms)
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(binding.TcParams) == 40
+    assert ctypes.sizeof(binding.TcHalo) == 72
+    assert ctypes.sizeof(binding.TcIterLog) == 40
+    assert ctypes.sizeof(binding.TcDensityStats) == 32
+
+
+def test_no_gpu_fails_loudly():
+    """Without a device the product raises; it never falls back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(binding.TcGpuError):
+        binding.TcGpu(0)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "toycluster_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "tc_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f

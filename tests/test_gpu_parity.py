@@ -1,0 +1,321 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C ABI of
+libtcgpu.so (toycluster_amd.binding -> include/tcgpu.h); the oracle is only the checker.
+
+Parity tiers:
+  T0 bit-exact : Peano keys, sort permutation / ids, iteration count, step schedule
+  T1 set-exact : neighbour sets for identical f32 inputs
+  T2 tolerance : |dpos| <= 1e-3 hsml, |drho|/rho <= 1e-3, |dhsml|/hsml <= 1e-3, errMean to 5 digits
+The only differences expected from the oracle are f64 summation order (1e-16 relative) and the
+device libm's pow() (<= 1 ulp f64), so single-pass results are compared far tighter than T2.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from toycluster_amd import binding, model as M
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TOL_POS = 1e-3     # in units of hsml
+TOL_RHO = 1e-3
+TOL_HSML = 1e-3
+
+
+def rel(a, b):
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.abs(b.astype(np.float64))
+
+
+# ------------------------------------------------------------------ T0: keys / sort
+
+def test_peano_known_answers_on_device(gpu):
+    kat = json.load(open(os.path.join(GOLDEN, "peano_kat.json")))["exact"]
+    xyz = np.array([e["xyz"] for e in kat], dtype=np.float64)
+    keys = gpu.Peano_Key(xyz)
+    for e, k in zip(kat, keys):
+        assert k == int(e["key"], 16), (e, hex(k))
+
+
+def test_peano_keys_random_vs_oracle(gpu):
+    rng = np.random.default_rng(1)
+    xyz = rng.random((20000, 3))
+    xyz[:50] = np.round(xyz[:50] * 8) / 8          # cell corners, incl. exact 0 and 1
+    keys = gpu.Peano_Key(xyz)
+    for p, k in zip(xyz[:3000], keys[:3000]):
+        assert k == O.peano_key(*p)
+
+
+def test_sort_is_bit_exact(gpu, golden_case):
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["pos"], c["ids"])
+    hi, lo = gpu.Sort_Particles_By_Peano_Key()
+    assert np.array_equal(hi, c["key_hi"]) and np.array_equal(lo, c["key_lo"])
+    p = gpu.particles()
+    assert np.array_equal(p["id"], c["ids"][c["perm"]])
+    assert np.array_equal(p["pos"], c["pos"][c["perm"]])
+
+
+def test_sort_with_duplicates_and_box_faces(gpu):
+    """Edge cases: duplicated positions (equal keys), coordinates exactly 0 and exactly boxsize."""
+    n = 5000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=21)
+    pos[100:110] = pos[100]                         # ties
+    pos[200, 0] = 0.0
+    pos[201, 1] = np.float32(m.boxsize)             # "orphan": X = 2^63 (peano.c:134-136)
+    pos[202] = np.float32(m.boxsize)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    hi, lo = gpu.Sort_Particles_By_Peano_Key()
+    k = [(int(h) << 64) | int(l) for h, l in zip(hi, lo)]
+    assert all(a <= b for a, b in zip(k[:-1], k[1:]))
+    o = O.Oracle(m, pos, ids)
+    ohi, olo, _ = o.sort_by_peano_key()
+    assert np.array_equal(hi, ohi) and np.array_equal(lo, olo)
+    p = gpu.particles()
+    assert sorted(p["id"]) == sorted(ids)
+    # neighbour queries stay exact with orphans present (brute-force oracle: wvt_relax.c:296-340)
+    gpu.build_neighbour_index()
+    og = O.Oracle(m, p["pos"], p["id"])
+    for i in list(range(0, n, 250)) + [int(np.where(p["id"] == ids[202])[0][0])]:
+        for h in (300.0, 900.0, 2500.0):
+            a = gpu.Find_ngb_tree(i, h)
+            b = og.find_ngb_simple(i, h)
+            assert np.array_equal(a, b), (i, h, len(a), len(b))
+
+
+# ------------------------------------------------------------------ T1: neighbour sets
+
+def test_neighbour_sets_exact(gpu, golden_case):
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["pos"], c["ids"])
+    gpu.build_neighbour_index()
+    for k, (i, h) in enumerate(zip(c["ngb_probe"], c["ngb_hsml"])):
+        got = gpu.Find_ngb_tree(int(i), float(h))
+        want = c["ngb_lists"][c["ngb_offsets"][k]:c["ngb_offsets"][k + 1]]
+        assert np.array_equal(got, want), (i, h, len(got), len(want))
+
+
+def test_neighbour_sets_all_radii(gpu):
+    """From 0.2% of the box to beyond the half box (periodic wrap, whole-box coverage)."""
+    n = 8000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=4)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    gpu.build_neighbour_index()
+    p = gpu.particles()
+    o = O.Oracle(m, p["pos"], p["id"])
+    rng = np.random.default_rng(2)
+    for i in rng.integers(0, n, 25):
+        for f in (0.002, 0.01, 0.03, 0.1, 0.3, 0.49, 0.55, 0.9):
+            a = gpu.Find_ngb_tree(int(i), f * m.boxsize)
+            b = o.find_ngb_simple(int(i), f * m.boxsize)
+            assert np.array_equal(a, b), (i, f, len(a), len(b))
+
+
+def test_guess_hsml_matches_reference_tree(gpu, golden_case):
+    """tree.c:113-121 evaluated without building the tree == the serial tree's answer."""
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["pos"], c["ids"])
+    g = gpu.Guess_hsml()
+    bad = np.flatnonzero(g != c["guess"])
+    assert len(bad) == 0, (len(bad), bad[:10], g[bad[:10]], c["guess"][bad[:10]])
+
+
+def test_guess_hsml_larger_case(gpu):
+    n = 60000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=17)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    g = gpu.Guess_hsml()
+    o = O.Oracle(m, pos, ids)
+    o.sort_by_peano_key()
+    o.build_tree()
+    want = np.array([o.guess_hsml(i) for i in range(n)], np.float32)
+    assert np.array_equal(g, want), int((g != want).sum())
+
+
+# ------------------------------------------------------------------ T2: density pass
+
+def test_density_model(gpu, golden_case):
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["d_pos"], c["d_ids"])
+    got = gpu.Global_density_model()
+    assert rel(got, c["d_rho_model"]).max() < 2e-7          # device pow() vs glibc pow(), f32 result
+
+
+def test_density_pass_cold(gpu, golden_case):
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["pos"], c["ids"])                          # hsml = 0: first-pass guess path
+    gpu.Find_sph_quantities()
+    p = gpu.particles()
+    assert np.array_equal(p["id"], c["d_ids"])
+    assert rel(p["hsml"], c["d_hsml"]).max() < 1e-6
+    assert rel(p["rho"], c["d_rho"]).max() < 1e-6
+    assert np.abs(p["varhsmlfac"] - c["d_vhf"]).max() < 1e-5
+    # nearly all values are bit-identical (only f64 summation order differs)
+    assert (p["hsml"] == c["d_hsml"]).mean() > 0.99
+    assert (p["rho"] == c["d_rho"]).mean() > 0.99
+
+
+def test_density_pass_warm_and_idempotent(gpu):
+    n = 30000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=8)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    gpu.set_option("stats", 1)
+    gpu.Find_sph_quantities()
+    cold = gpu.density_stats()
+    p1 = gpu.particles()
+    gpu.Find_sph_quantities()                               # warm start from the carried hsml
+    warm = gpu.density_stats()
+    gpu.set_option("stats", 0)
+    p2 = gpu.particles()
+    o = O.Oracle(m, pos, ids)
+    o.find_sph_quantities()
+    so_cold = o.last_stats()
+    q1 = o.particles()
+    o.find_sph_quantities()
+    so_warm = o.last_stats()
+    q2 = o.particles()
+    for p, q in ((p1, q1), (p2, q2)):
+        assert np.array_equal(p["id"], q["id"])
+        assert rel(p["hsml"], q["hsml"]).max() < 1e-6 and rel(p["rho"], q["rho"]).max() < 1e-6
+    # same control flow as the reference: same number of queries and solver iterations per particle
+    for a, b in ((cold, so_cold), (warm, so_warm)):
+        assert a["queries"] == pytest.approx(b["queries"], rel=1e-3)
+        assert a["solver_iters"] == pytest.approx(b["solver_iters"], rel=1e-3)
+        assert a["pair_evals"] == pytest.approx(b["pair_evals"], rel=1e-3)
+    # idempotence: a warm pass moves hsml only inside the +-0.05-neighbour band
+    assert rel(p2["hsml"], p1["hsml"]).max() < 2e-4
+
+
+# ------------------------------------------------------------------ T2: WVT sweep
+
+def test_wvt_sweep_single_step(gpu, golden_case):
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["pos"], c["ids"])
+    gpu.Find_sph_quantities()
+    hs, de = gpu.wvt_step(0.0085, move=False)
+    assert rel(hs, c["w_hsml"]).max() < 3e-7
+    scale = np.abs(c["w_delta"]).max()
+    # reference accumulates in f32 (one rounding per neighbour); we round once: <= ~1e-6 of the scale
+    assert np.abs(de - c["w_delta"]).max() < 2e-6 * scale
+
+
+def test_relaxation_short(gpu, golden_case):
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["pos"], c["ids"])
+    log = gpu.Regularise_sph_particles(max_iter=3)
+    want = c["r_log"]
+    assert len(log) == len(want)
+    for l, w in zip(log, want):
+        assert l["it"] == int(w[0]) and l["step"] == w[4]
+        assert l["err_mean"] == pytest.approx(w[2], rel=1e-5)
+        assert l["err_max"] == pytest.approx(w[1], rel=1e-3)
+    p = gpu.particles()
+    assert np.array_equal(p["id"], c["r_ids"])
+    assert (np.abs(p["pos"] - c["r_pos"]).max(axis=1) / c["r_hsml"]).max() < TOL_POS
+    assert rel(p["hsml"], c["r_hsml"]).max() < TOL_HSML and rel(p["rho"], c["r_rho"]).max() < TOL_RHO
+
+
+def test_relaxation_to_convergence_matches_oracle(gpu):
+    """Config-1-shaped run at a size the oracle finishes in seconds: identical iteration count, step
+    schedule and log to 5 digits; positions/densities inside T2 after the whole loop."""
+    n = 20000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=1)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    log = gpu.Regularise_sph_particles()
+    o = O.Oracle(m, pos, ids)
+    olog = o.regularise()
+    assert len(log) == len(olog)
+    for a, b in zip(log, olog):
+        assert a["it"] == b["it"] and a["step"] == b["step"]
+        assert a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-5)
+    p, q = gpu.particles(), o.particles()
+    assert np.array_equal(p["id"], q["id"])
+    dpos = np.abs(p["pos"] - q["pos"]).max(axis=1) / q["hsml"]
+    assert dpos.max() < TOL_POS and dpos.mean() < 1e-5
+    assert rel(p["hsml"], q["hsml"]).max() < TOL_HSML and rel(p["rho"], q["rho"]).max() < TOL_RHO
+
+
+# ------------------------------------------------------------------ T2: curl
+
+def test_curl_of_vector_potential(gpu, golden_case):
+    c = golden_case
+    gpu.set_model(c["model"])
+    gpu.upload(c["pos"], c["ids"])
+    gpu.Find_sph_quantities()
+    b = gpu.Bfld_from_rotA_SPH(c["c_apot"])
+    scale = np.abs(c["c_bfld"]).max()
+    assert np.abs(b - c["c_bfld"]).max() < 1e-5 * scale
+
+
+# ------------------------------------------------------------------ error behaviour
+
+def test_out_of_box_coordinate_is_reported(gpu):
+    n = 2000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=2)
+    pos[5, 0] = -1.0
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    with pytest.raises(binding.TcGpuError, match="COORD_RANGE"):
+        gpu.Find_sph_quantities()
+    pos[5, 0] = np.nan
+    gpu.upload(pos, ids)
+    with pytest.raises(binding.TcGpuError, match="COORD_RANGE"):
+        gpu.Find_sph_quantities()
+
+
+# ------------------------------------------------------------------ full-size properties (config 2)
+
+def test_full_size_properties(gpu):
+    """BASELINE config 2 size (2e6 gas, 2-cluster merger): size-independent properties."""
+    n = 2_000_000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=14041981)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    log = gpu.Regularise_sph_particles(max_iter=2)
+    assert len(log) == 3 and log[2]["err_mean"] < log[0]["err_mean"]
+    hi, lo = gpu.Sort_Particles_By_Peano_Key()
+    assert np.all(hi[1:] >= hi[:-1])                                   # sortedness
+    p = gpu.particles()
+    assert np.array_equal(np.sort(p["id"]), np.sort(ids))               # ids are a permutation
+    assert p["pos"].min() >= 0 and p["pos"].max() <= m.boxsize
+    assert np.all(np.isfinite(p["hsml"])) and p["hsml"].min() > 0 and p["rho"].min() > 0
+    # kernel-weighted neighbour number of sampled particles is 295 +- 0.05 (brute force, numpy)
+    gpu.Find_sph_quantities()
+    p = gpu.particles()
+    P = p["pos"].astype(np.float64)
+    for i in range(0, n, n // 16):
+        d = P - P[i]
+        d -= m.boxsize * np.round(d / m.boxsize)
+        r = np.sqrt((d * d).sum(axis=1))
+        h = float(p["hsml"][i])
+        u = np.minimum(r / h, 1.0)
+        w = 1365.0 / (64 * np.pi) / h ** 3 * (1 - u) ** 8 * (1 + 8 * u + 25 * u * u + 32 * u ** 3)
+        assert abs((4.18879032135009765 * w * h ** 3).sum() - 295) < 0.06
+    # oracle spot check at full size: neighbour sets of a few particles (brute force)
+    o = O.Oracle(m, p["pos"], p["id"])
+    for i in (0, n // 3, n - 1):
+        a = gpu.Find_ngb_tree(i, float(p["hsml"][i]))
+        b = o.find_ngb_simple(i, float(p["hsml"][i]))
+        assert np.array_equal(a, b)

@@ -1,0 +1,131 @@
+"""CPU tests of the oracle (the checker itself): known answers, internal consistency, and the
+committed golden vectors.  No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from toycluster_amd import model as M
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_peano_known_answers():
+    """keys captured from the compiled reference peano.c."""
+    kat = json.load(open(os.path.join(GOLDEN, "peano_kat.json")))["exact"]
+    for e in kat:
+        x, y, z = e["xyz"]
+        assert O.peano_key(x, y, z) == int(e["key"], 16), e
+        rk = O.reversed_peano_key(x, y, z)
+        if "rkey" in e:
+            assert rk == int(e["rkey"], 16), e
+        else:
+            h = hex(rk)
+            assert h.startswith(e["rkey_prefix"]) and h.endswith(e["rkey_suffix"]), (h, e)
+            body = h[len(e["rkey_prefix"]):-len(e["rkey_suffix"])]
+            assert set(body) <= set(e["rkey_repeat"]) and len(h) == 34, h
+
+
+def test_key_is_hilbert_curve():
+    """Consecutive cells along the key order are face neighbours (Hilbert property), level 3."""
+    n = 8
+    pts = [((i + .5) / n, (j + .5) / n, (k + .5) / n) for i in range(n) for j in range(n) for k in range(n)]
+    keys = [O.peano_key(*p) for p in pts]
+    order = np.argsort(np.array([k >> 64 for k in keys], dtype=np.uint64), kind="stable")
+    assert len(set(keys)) == n ** 3
+    p = np.array(pts)[order]
+    d = np.abs(np.diff(p, axis=0)).sum(axis=1)
+    assert np.allclose(d, 1.0 / n)
+
+
+def test_sort_matches_numpy_and_tree_matches_bruteforce():
+    n = 4000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=3)
+    o = O.Oracle(m, pos, ids)
+    hi, lo, perm = o.sort_by_peano_key()
+    keys = [O.peano_key(*(pos[i].astype(np.float64) / m.boxsize)) for i in range(n)]
+    expect = sorted(range(n), key=lambda i: keys[i])
+    assert list(perm) == expect                       # tie-free input: the permutation is unique
+    assert [(int(h) << 64) | int(l) for h, l in zip(hi, lo)] == [keys[i] for i in expect]
+    p = o.particles()
+    assert np.array_equal(p["id"], ids[perm]) and np.array_equal(p["pos"], pos[perm])
+
+    nn = o.build_tree()
+    t = o.tree_nodes()
+    leaf = t["dnext"] < 0
+    assert 0.3 * n < nn < 0.7 * n
+    assert t["npart"][leaf].max() <= 8 and t["npart"][leaf].sum() == n      # tree.c:201-226
+    first = -(t["dnext"][leaf] + 1)
+    assert np.array_equal(np.sort(first), np.cumsum(np.r_[0, t["npart"][leaf][np.argsort(first)]])[:-1])
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, n, 40):
+        g = o.guess_hsml(i)
+        for f in (0.4, 1.0, 1.7):
+            a, b = o.find_ngb_tree(i, g * f), o.find_ngb_simple(i, g * f)
+            assert np.array_equal(a, b)                # same set AND ascending order
+            assert np.all(np.diff(a) > 0)
+
+
+def test_density_pass_reaches_tolerance_band():
+    """Every converged particle has 295 +- 0.05 kernel-weighted neighbours (globals.h:48-49)."""
+    n = 3000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=5)
+    o = O.Oracle(m, pos, ids)
+    o.find_sph_quantities()
+    p = o.particles()
+    assert np.all(np.isfinite(p["hsml"])) and np.all(p["hsml"] > 0) and np.all(p["rho"] > 0)
+    box = m.boxsize
+    for i in range(0, n, 97):
+        d = p["pos"][i].astype(np.float64) - p["pos"].astype(np.float64)
+        d -= box * np.round(d / box)
+        r = np.sqrt((d * d).sum(axis=1))
+        h = float(p["hsml"][i])
+        u = np.minimum(r / h, 1.0)
+        w = 1365.0 / (64 * np.pi) / h ** 3 * (1 - u) ** 8 * (1 + 8 * u + 25 * u * u + 32 * u ** 3)
+        nngb = (4.18879032135009765 * w * h ** 3).sum()
+        assert abs(nngb - 295) < 0.06, (i, nngb)
+
+
+def test_golden_vectors(golden_case):
+    """The oracle still reproduces the committed vectors bit for bit (regression pin)."""
+    c = golden_case
+    m = c["model"]
+    o = O.Oracle(m, c["pos"], c["ids"])
+    hi, lo, perm = o.sort_by_peano_key()
+    assert np.array_equal(hi, c["key_hi"]) and np.array_equal(lo, c["key_lo"]) and np.array_equal(perm, c["perm"])
+    o = O.Oracle(m, c["pos"], c["ids"])
+    o.find_sph_quantities()
+    p = o.particles()
+    assert np.array_equal(p["id"], c["d_ids"])
+    assert np.array_equal(p["hsml"], c["d_hsml"]) and np.array_equal(p["rho"], c["d_rho"])
+    assert np.array_equal(p["varhsmlfac"], c["d_vhf"])
+    assert np.array_equal(o.global_density_model(), c["d_rho_model"])
+    hs, de = o.wvt_step(0.0085, move=False)
+    assert np.array_equal(hs, c["w_hsml"]) and np.array_equal(de, c["w_delta"])
+    o.set_apot(c["c_apot"])
+    assert np.array_equal(o.bfld_from_rotA(), c["c_bfld"])
+
+
+def test_relaxation_log_and_stop_rule():
+    """Loop semantics of wvt_relax.c:61-104: it = 0..; diff(0) = inf; step *= 0.8 rule; >= 12 lines."""
+    n = 6000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=9)
+    o = O.Oracle(m, pos, ids)
+    log = o.regularise()
+    assert [l["it"] for l in log] == list(range(len(log)))
+    assert np.isinf(log[0]["err_diff"]) and log[0]["step"] == 0.0085
+    assert 12 <= len(log) <= 65
+    for a, b in zip(log[:-1], log[1:]):
+        shrink = a["err_diff"] < 0.01 and a["it"] > 1
+        assert b["step"] == pytest.approx(a["step"] * (0.8 if shrink else 1.0), rel=1e-15)
+    last, prev = log[-1], log[-2]
+    assert (last["err_diff"] < 0.01 and last["it"] > 25) or (last["err_diff"] < 0 and prev["err_diff"] < 0 and last["it"] > 10)
+    p = o.particles()
+    assert sorted(p["id"]) == sorted(ids)
+    assert p["pos"].min() >= 0 and p["pos"].max() <= m.boxsize
+    assert O.format_log_line(log[1]).startswith("   #01: Err max=")

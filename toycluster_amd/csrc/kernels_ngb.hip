@@ -1,0 +1,591 @@
+/*
+ * kernels_ngb.hip -- the neighbour-gather kernels (one 64-lane wavefront per particle):
+ *   K5  hsml / density solve      src/sph.c:13-214   (+ ball query src/tree.c:25-111)
+ *   K9  WVT displacement sweep    src/wvt_relax.c:126-171
+ *   K11 SPH curl of A             src/sph.c:216-300
+ *
+ * Ball query.  The reference walks its octree and tests leaf particles with an all-f32
+ * predicate (src/tree.c:67-89).  Here the query picks the cell-table level whose cell edge s
+ * satisfies s < h <= 2s, enumerates the <= 6^3 cells overlapping [x-h, x+h]^3 (periodic), drops
+ * cells farther than h from the particle, and streams the contiguous particle run of every
+ * remaining cell through the same f32 predicate, 64 candidates per step (coalesced float4
+ * loads).  The result set equals the reference's; its order is not ascending, which only
+ * permutes f64 summation order (DESIGN.md "Numerics").
+ *
+ * Hits are compacted with ballot + mbcnt into a per-wave LDS list holding the f64 pair
+ * distance r, on which the reference's Newton-Raphson / bisection control flow then runs
+ * with 64-lane partial sums and butterfly reductions.
+ */
+#include "tc_ctx.h"
+
+#define WPB TC_WAVES_PER_BLOCK
+#define TBN (WPB * 64)
+
+/* ------------------------------------------------------------------ wave helpers */
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int mask_rank(uint64_t m) /* set bits below this lane */
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+/* wave-uniform copy of a double (lets the compiler keep dependent control flow scalar) */
+__device__ __forceinline__ double bcast0(double v)
+{
+    uint64_t u = __builtin_bit_cast(uint64_t, v);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+/* butterfly sum: every lane ends with the same bits (IEEE add is commutative) */
+__device__ __forceinline__ double wsum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return bcast0(v);
+}
+
+/* ------------------------------------------------------------------ query geometry */
+
+struct tc_query {
+    int L, nL;            /* level, cells per dimension */
+    int lo[3], nd[3];     /* first cell (unwrapped, may be negative) and cell count per dim */
+    bool full[3];         /* the dimension covers the whole ring: no culling there */
+    double s, hp;         /* cell edge, padded radius */
+    size_t off;           /* table offset of the level */
+};
+
+__device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, float yi, float zi, float h, tc_query &q)
+{
+    /* level with s < h <= 2s : L = floor(log2(box/h)) + 1 */
+    double ratio = k.boxsize / (double)h;
+    int L = (ratio >= 1.0) ? (ilogb(ratio) + 1) : 1;
+    L += k.level_shift;
+    if (L < 1) L = 1;
+    if (L > k.lmax) L = k.lmax;
+    q.L = L;
+    q.nL = 1 << L;
+    q.s = k.boxsize / (double)q.nL;
+    q.off = tc_level_offset(L);
+    /* pad: the f32 predicate can accept pairs a few ulp beyond h */
+    q.hp = (double)h * (1.0 + 1e-5) + k.boxsize * 1e-7;
+    const float xs[3] = {xi, yi, zi};
+    const bool huge = !(q.hp < k.boxsize);      /* ball wider than the box: take every cell once */
+    for (int d = 0; d < 3; d++) {
+        int lo = 0, nd = q.nL;
+        if (!huge) {
+            lo = (int)floor(((double)xs[d] - q.hp) / q.s);
+            int hi = (int)floor(((double)xs[d] + q.hp) / q.s);
+            nd = hi - lo + 1;
+        }
+        q.full[d] = false;
+        if (nd >= q.nL) { nd = q.nL; lo = 0; q.full[d] = true; }
+        q.lo[d] = lo; q.nd[d] = nd;
+    }
+}
+
+/* Per-lane cell c of the query block: returns the particle run [st,en) (empty if culled). */
+__device__ __forceinline__ void query_cell(const tc_dev_const &k, const tc_query &q, float xi, float yi, float zi,
+                                           int c, uint32_t &st, uint32_t &en)
+{
+    st = en = 0;
+    int nyz = q.nd[1] * q.nd[2];
+    int a = c / nyz, r = c - a * nyz;
+    int b = r / q.nd[2], cc = r - b * q.nd[2];
+    const int off[3] = {a, b, cc};
+    const float xs[3] = {xi, yi, zi};
+    double g2 = 0;
+    size_t lin = 0;
+    for (int d = 0; d < 3; d++) {
+        int u = q.lo[d] + off[d];                 /* unwrapped cell coordinate */
+        if (!q.full[d]) {
+            double clo = (double)u * q.s, chi = clo + q.s;
+            double x = (double)xs[d];
+            double g = x < clo ? clo - x : (x > chi ? x - chi : 0.0);
+            g2 += g * g;
+        }
+        lin = lin * (size_t)q.nL + (size_t)(u & (q.nL - 1));
+    }
+    if (g2 > q.hp * q.hp) return;
+    uint32_t s0 = k.cstart[q.off + lin], e0 = k.cend[q.off + lin];
+    if (e0 > s0) { st = s0; en = e0; }
+}
+
+__device__ __forceinline__ bool is_orphan(const tc_dev_const &k, float4 p)
+{
+    return (double)p.x >= k.boxsize || (double)p.y >= k.boxsize || (double)p.z >= k.boxsize;
+}
+
+/*
+ * Stream every candidate of the ball (xi,h) through `body(j, p, active)`; body is called
+ * wave-uniformly (all 64 lanes, `active` false for padding lanes) and returns true to stop.
+ * Returns the number of candidates streamed (for the work counters).
+ */
+template <class Body>
+__device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, float xi, float yi, float zi, float h,
+                                                      Body &&body)
+{
+    const int lane = lane_id();
+    tc_query q;
+    query_setup(k, xi, yi, zi, h, q);
+    const int ncell = q.nd[0] * q.nd[1] * q.nd[2];
+    int norph = *k.norph;
+    if (norph > TC_MAX_ORPHANS) norph = TC_MAX_ORPHANS;   /* overflow is flagged by k_cells */
+    uint32_t ncand = 0;
+
+    for (int base = 0; base < ncell; base += 64) {
+        uint32_t st = 0, en = 0;
+        if (base + lane < ncell) query_cell(k, q, xi, yi, zi, base + lane, st, en);
+        uint64_t m = __ballot(en > st);
+        while (m) {
+            int l = __builtin_ctzll(m);
+            m &= m - 1;
+            uint32_t s0 = __shfl(st, l), e0 = __shfl(en, l);
+            ncand += e0 - s0;
+            for (uint32_t j0 = s0; j0 < e0; j0 += 64) {
+                uint32_t j = j0 + lane;
+                bool act = j < e0;
+                float4 p = k.pos4[act ? j : s0];
+                if (norph && act && is_orphan(k, p)) act = false;
+                if (body((int)j, p, act)) return ncand;
+            }
+        }
+    }
+    for (int o0 = 0; o0 < norph; o0 += 64) {        /* orphans: brute force */
+        int o = o0 + lane;
+        bool act = o < norph;
+        uint32_t j = k.orphans[act ? o : 0];
+        float4 p = k.pos4[j];
+        if (body((int)j, p, act)) return ncand;
+    }
+    return ncand + norph;
+}
+
+/* ------------------------------------------------------------------ K5 density */
+
+struct tc_density_args {
+    tc_dev_const k;
+    const float *hsml_in;      /* carried smoothing lengths (0 => use guess) */
+    const float *guess;        /* may be NULL when no particle has hsml == 0 */
+    float *hsml_out, *rho_out, *vhf_out;
+    double bias_const;         /* -0.0116 * pow(DESNNGB*0.01, -2.236), host libm */
+    int *flags;
+    uint32_t *stats;           /* optional: 4 x n work counters */
+    int stats_stride;
+};
+
+/* src/sph.c:80-214 on the LDS list.  All lanes return identical values. */
+__device__ __forceinline__ bool solve_hsml(const double *__restrict__ rl, int cnt, double mpart, double bias_const,
+                                           float &hsml_io, float &rho_out, float &drho_io,
+                                           uint32_t &iters, uint32_t &pairs)
+{
+    const int lane = lane_id();
+    double upper = (double)hsml_io * TC_SQRT3;
+    double lower = 0;
+    double hsml = (double)hsml_io;
+    double rho = 0, dRhodHsml = 0;
+    int it = 0;
+    bool part_done = false;
+
+    for (;;) {
+        double wkNgb = 0;
+        rho = dRhodHsml = 0;
+        it++;
+        iters++;
+        pairs += cnt;
+
+        const float hf = (float)hsml;
+        const double norm_h3 = TC_WC6_NORM / (double)(hf * hf * hf);
+        const double norm_h4 = TC_WC6_NORM / (double)(hf * hf * hf * hf) * -22.0;
+        const double h3 = hsml * hsml * hsml;
+        const double three_h = 3 / hsml;
+        const double nmpart = -mpart;
+
+        for (int kk = lane; kk < cnt; kk += 64) {
+            double r = rl[kk];
+            if (r > hsml) continue;            /* == (r2 > hsml^2) up to a zero-weight boundary, DESIGN.md */
+            float rf = (float)r;
+            double wk = tc_wc6(rf, hf, norm_h3);
+            double dwk = tc_dwc6(rf, hf, norm_h4);
+            wkNgb += TC_FOURPITHIRD * wk * h3;
+            rho += mpart * wk;
+            dRhodHsml += nmpart * (three_h * wk + r / hsml * dwk);
+        }
+        wkNgb = wsum(wkNgb);
+        rho = wsum(rho);
+        dRhodHsml = wsum(dRhodHsml);
+
+        if (it > 128) break;
+
+        double ngbDev = fabs(wkNgb - TC_DESNNGB);
+        if (ngbDev < TC_NNGBDEV) { part_done = true; break; }
+
+        if (fabs(upper - lower) < 1e-4) { hsml *= 1.26; break; }
+
+        if (ngbDev < 0.5 * TC_DESNNGB) {
+            double omega = (1 + dRhodHsml * hsml / (3 * rho));
+            double fac = 1 - (wkNgb - TC_DESNNGB) / (3 * wkNgb * omega);
+            fac = fmin(1.24, fac);
+            fac = fmax(1 / 1.24, fac);
+            hsml *= fac;
+        } else {
+            if (wkNgb > TC_DESNNGB) upper = hsml;
+            if (wkNgb < TC_DESNNGB) lower = hsml;
+            hsml = pow(0.5 * ((lower * lower * lower) + (upper * upper * upper)), 1.0 / 3.0);
+        }
+    }
+
+    hsml_io = (float)hsml;
+    rho_out = (float)rho;
+    if (part_done) {
+        drho_io = (float)dRhodHsml;
+        const float hf = (float)hsml;
+        /* sph_kernel_WC6(0, hsml): u = 0, t = 1 */
+        float w0 = (float)(TC_WC6_NORM / (double)(hf * hf * hf));
+        double bias_corr = bias_const * mpart * w0;
+        rho_out = (float)((double)rho_out + bias_corr);
+    }
+    return part_done;
+}
+
+__global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    double *rl = reinterpret_cast<double *>(lds_raw) + (size_t)wave * TC_NGBMAX;
+    const tc_dev_const &k = a.k;
+
+    const int i = k.lo + blockIdx.x * WPB + wave;
+    if (i >= k.hi) return;
+
+    const float4 pi = k.pos4[i];
+    const float xi = pi.x, yi = pi.y, zi = pi.z;
+    float hsml = a.hsml_in[i];
+    if (hsml == 0) hsml = 2 * a.guess[i];                 /* src/sph.c:25-26 */
+    if (!isfinite(hsml)) {                                /* src/sph.c:28 */
+        if (lane == 0) atomicOr(&a.flags[0], 1);
+        return;
+    }
+
+    float dRhodHsml = 0, rho = 0;
+    uint32_t nq = 0, nit = 0, npair = 0, ncand = 0;
+    bool ok = false;
+
+    for (int guard = 0; guard < 4096; guard++) {
+        /* ---- ball query (src/tree.c:25-111), f32 predicate, list capped at NGBMAX */
+        const float h2 = hsml * hsml;
+        int cnt = 0;
+        nq++;
+        ncand += stream_candidates(k, xi, yi, zi, hsml, [&](int j, float4 p, bool act) -> bool {
+            float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+            bool hit = act && (r2 < h2);
+            uint64_t m = __ballot(hit);
+            if (hit) {
+                int slot = cnt + mask_rank(m);
+                if (slot < TC_NGBMAX) rl[slot] = tc_pair_r(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize);
+            }
+            cnt += __popcll(m);
+            return cnt >= TC_NGBMAX;
+        });
+        if (cnt >= TC_NGBMAX) { hsml = (float)((double)hsml / 1.24); continue; }   /* src/sph.c:42-47 */
+        if (cnt < TC_DESNNGB) { hsml = (float)((double)hsml * 1.23); continue; }   /* src/sph.c:49-54 */
+
+        if (solve_hsml(rl, cnt, k.mpart, a.bias_const, hsml, rho, dRhodHsml, nit, npair)) { ok = true; break; }
+        if (!isfinite(hsml)) break;
+    }
+    if (!ok) {
+        if (lane == 0) atomicOr(&a.flags[2], 1);
+    }
+    if (lane == 0) {
+        float varHsmlFac = (float)(1.0 / (double)(1 + hsml / (3 * rho) * dRhodHsml));   /* src/sph.c:66 */
+        a.hsml_out[i] = hsml;
+        a.rho_out[i] = rho;
+        a.vhf_out[i] = varHsmlFac;
+        if (a.stats) {
+            a.stats[i] = nq;
+            a.stats[i + (size_t)a.stats_stride] = nit;
+            a.stats[i + 2 * (size_t)a.stats_stride] = npair;
+            a.stats[i + 3 * (size_t)a.stats_stride] = ncand;
+        }
+    }
+}
+
+void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
+{
+    k->boxsize = c->par.boxsize;
+    k->boxhalf = 0.5 * c->par.boxsize;
+    k->mpart = c->par.mpart_gas;
+    k->boxsize_f = (float)c->par.boxsize;               /* src/tree.c:27 */
+    k->boxhalf_f = (float)(c->par.boxsize * 0.5);       /* src/tree.c:28 */
+    k->lmax = c->lmax;
+    k->level_shift = c->level_shift;
+    k->cstart = c->cstart;
+    k->cend = c->cend;
+    k->orphans = c->orphans;
+    k->norph = c->norph;
+    k->pos4 = c->pos4[c->cur];
+    k->n = (int)c->n;
+    int64_t lo = c->rank * c->shard_len, hi = (c->rank + 1) * c->shard_len;
+    if (hi > c->n) hi = c->n;
+    if (lo > hi) lo = hi;
+    k->lo = (int)lo;
+    k->hi = (int)hi;
+}
+
+int tc_launch_density(tcgpu_ctx *c)
+{
+    tc_density_args a;
+    tc_fill_const(c, &a.k);
+    a.hsml_in = c->hsml[c->cur];
+    a.guess = c->guess;
+    a.hsml_out = c->hsml[c->cur];
+    a.rho_out = c->rho[c->cur];
+    a.vhf_out = c->vhf[c->cur];
+    a.bias_const = -0.0116 * pow(TC_DESNNGB * 0.01, -2.236);   /* src/sph.c:206 */
+    a.flags = c->flags;
+    a.stats = c->want_stats ? c->stats : nullptr;
+    a.stats_stride = (int)c->cap;
+    int nloc = a.k.hi - a.k.lo;
+    if (nloc <= 0) return 0;
+    size_t lds = (size_t)WPB * TC_NGBMAX * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TC_HIP(c, hipFuncSetAttribute((const void *)k_density, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    tc_phase_begin(c, PH_DENSITY);
+    k_density<<<(nloc + WPB - 1) / WPB, TBN, lds, c->stream>>>(a);
+    tc_phase_end(c);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+/* ------------------------------------------------------------------ K9 WVT sweep */
+
+struct tc_wvt_args {
+    tc_dev_const k;
+    double step;
+    float *delta;       /* 3n xyz interleaved */
+    int *flags;
+};
+
+/* accumulate one neighbour's contribution, src/wvt_relax.c:144-169 */
+__device__ __forceinline__ void wvt_pair(const float4 pi, const float4 pj, double boxinv, double step_hi,
+                                         double &d0, double &d1, double &d2)
+{
+    float dx = (float)((double)(pi.x - pj.x) * boxinv);
+    float dy = (float)((double)(pi.y - pj.y) * boxinv);
+    float dz = (float)((double)(pi.z - pj.z) * boxinv);
+    dx = (double)dx > 0.5 ? (float)((double)dx - 1) : dx;
+    dy = (double)dy > 0.5 ? (float)((double)dy - 1) : dy;
+    dz = (double)dz > 0.5 ? (float)((double)dz - 1) : dz;
+    dx = (double)dx < -0.5 ? (float)((double)dx + 1) : dx;
+    dy = (double)dy < -0.5 ? (float)((double)dy + 1) : dy;
+    dz = (double)dz < -0.5 ? (float)((double)dz + 1) : dz;
+    float r2 = (dx * dx + dy * dy + dz * dz);
+    float h = (float)(0.5 * (double)(pi.w + pj.w));
+    if (r2 > h * h) return;
+    float r = (float)sqrt((double)r2);
+    float wk = (float)tc_wvt_wc6(r, h);
+    double base = step_hi * (double)wk;          /* (step * hsml_i) * wk */
+    d0 += base * (double)dx / (double)r;
+    d1 += base * (double)dy / (double)r;
+    d2 += base * (double)dz / (double)r;
+}
+
+__global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const tc_dev_const &k = a.k;
+    const int i = k.lo + blockIdx.x * WPB + wave;
+    if (i >= k.hi) return;
+
+    const float4 pi = k.pos4[i];
+    const double boxinv = 1 / k.boxsize;
+    const float hq = (float)((double)pi.w * k.boxsize);      /* src/wvt_relax.c:135 */
+    const float hq2 = hq * hq;
+    const double step_hi = a.step * (double)pi.w;
+
+    double d0 = 0, d1 = 0, d2 = 0;
+    int cnt = 0;
+    stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+        float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+        bool hit = act && (r2 < hq2);
+        cnt += __popcll(__ballot(hit));
+        if (hit && j != i) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
+        return false;
+    });
+
+    if (cnt >= TC_NGBMAX) {
+        /* The reference truncates the list to the first NGBMAX hits in ascending index
+         * (src/tree.c:91-92).  Find the index threshold T with exactly NGBMAX hits below it
+         * by bisection over re-gathers, then redo the sum with j < T.  Never seen in practice. */
+        if (lane == 0) atomicAdd(&a.flags[4], 1);
+        int tlo = 0, thi = k.n;                      /* count(j < tlo) < NGBMAX <= count(j < thi) */
+        while (thi - tlo > 1) {
+            int mid = tlo + ((thi - tlo) >> 1);
+            int cm = 0;
+            stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+                float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+                cm += __popcll(__ballot(act && (r2 < hq2) && j < mid));
+                return false;
+            });
+            if (cm >= TC_NGBMAX) thi = mid; else tlo = mid;
+        }
+        d0 = d1 = d2 = 0;
+        stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+            float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+            if (act && (r2 < hq2) && j < thi && j != i) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
+            return false;
+        });
+    }
+
+    d0 = wsum(d0); d1 = wsum(d1); d2 = wsum(d2);
+    if (lane == 0) {
+        a.delta[3 * (size_t)i] = (float)d0;
+        a.delta[3 * (size_t)i + 1] = (float)d1;
+        a.delta[3 * (size_t)i + 2] = (float)d2;
+    }
+}
+
+int tc_launch_wvt(tcgpu_ctx *c, double step)
+{
+    tc_wvt_args a;
+    tc_fill_const(c, &a.k);
+    a.step = step;
+    a.delta = c->delta;
+    a.flags = c->flags;
+    int nloc = a.k.hi - a.k.lo;
+    if (nloc <= 0) return 0;
+    tc_phase_begin(c, PH_WVT);
+    k_wvt<<<(nloc + WPB - 1) / WPB, TBN, 0, c->stream>>>(a);
+    tc_phase_end(c);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+/* ------------------------------------------------------------------ K11 curl(A) */
+
+struct tc_curl_args {
+    tc_dev_const k;
+    const float *hsml, *rho, *vhf;
+    const float *apot;     /* 3n */
+    float *bfld;           /* 3n */
+};
+
+/* src/sph.c:224-295 */
+__global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const tc_dev_const &k = a.k;
+    const int i = k.lo + blockIdx.x * WPB + wave;
+    if (i >= k.hi) return;
+
+    const float4 pi = k.pos4[i];
+    const float hq = a.hsml[i];
+    const float hq2 = hq * hq;
+    const double hsml = hq, rho_i = a.rho[i], vhf = a.vhf[i];
+    const double ax = a.apot[3 * (size_t)i], ay = a.apot[3 * (size_t)i + 1], az = a.apot[3 * (size_t)i + 2];
+    const double norm_h4 = TC_WC6_NORM / (double)(hq * hq * hq * hq) * -22.0;
+    const double nm_rho = -k.mpart / rho_i;
+    double b0 = 0, b1 = 0, b2 = 0;
+    int cnt = 0;
+    int thi = k.n;
+
+    for (int pass = 0; pass < 2; pass++) {
+        cnt = 0; b0 = b1 = b2 = 0;
+        stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+            float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+            bool hit = act && (r2f < hq2) && j < thi;
+            cnt += __popcll(__ballot(hit));
+            if (hit && j != i) {
+                double dx = (double)pi.x - (double)p.x, dy = (double)pi.y - (double)p.y, dz = (double)pi.z - (double)p.z;
+                if (dx > k.boxhalf) dx -= k.boxsize;
+                if (dx < -k.boxhalf) dx += k.boxsize;
+                if (dy > k.boxhalf) dy -= k.boxsize;
+                if (dy < -k.boxhalf) dy += k.boxsize;
+                if (dz > k.boxhalf) dz -= k.boxsize;
+                if (dz < -k.boxhalf) dz += k.boxsize;
+                double r2 = dx * dx + dy * dy + dz * dz;
+                if (!(r2 > hsml * hsml)) {
+                    double r = sqrt(r2);
+                    double dwk = tc_dwc6((float)r, hq, norm_h4);
+                    double weight = nm_rho * dwk / r * vhf;
+                    double dAx = ax - (double)a.apot[3 * (size_t)j];
+                    double dAy = ay - (double)a.apot[3 * (size_t)j + 1];
+                    double dAz = az - (double)a.apot[3 * (size_t)j + 2];
+                    b0 += weight * (dz * dAy - dy * dAz);
+                    b1 += weight * (dx * dAz - dz * dAx);
+                    b2 += weight * (dy * dAx - dx * dAy);
+                }
+            }
+            return false;
+        });
+        if (cnt < TC_NGBMAX || pass == 1) break;
+        /* list truncation as in k_wvt: find the ascending-index threshold, then redo */
+        int tlo = 0;
+        thi = k.n;
+        while (thi - tlo > 1) {
+            int mid = tlo + ((thi - tlo) >> 1);
+            int cm = 0;
+            stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+                float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+                cm += __popcll(__ballot(act && (r2f < hq2) && j < mid));
+                return false;
+            });
+            if (cm >= TC_NGBMAX) thi = mid; else tlo = mid;
+        }
+    }
+    b0 = wsum(b0); b1 = wsum(b1); b2 = wsum(b2);
+    if (lane == 0) {
+        a.bfld[3 * (size_t)i] = (float)b0;
+        a.bfld[3 * (size_t)i + 1] = (float)b1;
+        a.bfld[3 * (size_t)i + 2] = (float)b2;
+    }
+}
+
+int tc_launch_curl(tcgpu_ctx *c)
+{
+    tc_curl_args a;
+    tc_fill_const(c, &a.k);
+    a.hsml = c->hsml[c->cur];
+    a.rho = c->rho[c->cur];
+    a.vhf = c->vhf[c->cur];
+    a.apot = c->apot;
+    a.bfld = c->bfld;
+    int nloc = a.k.hi - a.k.lo;
+    if (nloc <= 0) return 0;
+    tc_phase_begin(c, PH_CURL);
+    k_curl<<<(nloc + WPB - 1) / WPB, TBN, 0, c->stream>>>(a);
+    tc_phase_end(c);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+/* ------------------------------------------------------------------ single ball query (API / tests) */
+
+__global__ __launch_bounds__(64) void k_find_ngb(tc_dev_const k, int i, float hsml, int32_t *out, int *count)
+{
+    const float4 pi = k.pos4[i];
+    const float h2 = hsml * hsml;
+    int cnt = 0;
+    stream_candidates(k, pi.x, pi.y, pi.z, hsml, [&](int j, float4 p, bool act) -> bool {
+        float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+        bool hit = act && (r2 < h2);
+        uint64_t m = __ballot(hit);
+        if (hit) out[cnt + mask_rank(m)] = j;
+        cnt += __popcll(m);
+        return false;
+    });
+    if (lane_id() == 0) *count = cnt;
+}
+
+int tc_launch_find_ngb(tcgpu_ctx *c, int ipart, float hsml)
+{
+    tc_dev_const k;
+    tc_fill_const(c, &k);
+    k_find_ngb<<<1, 64, 0, c->stream>>>(k, ipart, hsml, c->ngb_buf, c->ngb_cnt);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,216 @@
+/*
+ * tc_math.h -- scalar arithmetic shared by all kernels of libtcgpu (gfx950).
+ *
+ * Everything here is a pure function of its arguments and is marked TC_HD so the
+ * very same lines can be unit-checked on the host (tests/hostcheck) as well as run
+ * inside the HIP kernels.  The library must be compiled with -ffp-contract=off:
+ * the reference (gcc -std=c99, baseline x86-64) never fuses a multiply-add, and the
+ * f32 ball-query predicate decides set membership.
+ *
+ * Reference lines whose arithmetic is reproduced are cited per function
+ * (reference = jdonnert/Toycluster, paths relative to src/).
+ */
+#ifndef TC_MATH_H
+#define TC_MATH_H
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define TC_HD __host__ __device__ __forceinline__
+#else
+#define TC_HD static inline
+#endif
+
+#define TC_DESNNGB 295              /* globals.h:48 */
+#define TC_NNGBDEV 0.05             /* globals.h:49 */
+#define TC_NGBMAX (TC_DESNNGB * 8)  /* globals.h:50 */
+#define TC_NUMITER 64               /* wvt_relax.c:7 */
+#define TC_ERRDIFF_LIMIT 0.01       /* wvt_relax.c:8 */
+#define TC_NTRIPLETS 42             /* peano.h:1 */
+#define TC_MAXHALOS 4096            /* globals.h:56 */
+
+#define TC_PI 3.14159265358979323846
+#define TC_SQRT3 1.73205080756887719        /* globals.h:62 */
+#define TC_FOURPITHIRD 4.18879032135009765  /* globals.h:63 */
+#define TC_WC6_NORM (1365.0 / (64 * TC_PI)) /* sph.c:431 */
+
+typedef unsigned __int128 tc_u128;
+
+/* ------------------------------------------------------------------ Peano-Hilbert */
+
+/* Integer coordinates of a particle: X = trunc(x * 2^63) with x = (double)pos / box
+ * (peano.c:66-68,134-136).  Axis order of the transpose array is {y, z, x}. */
+TC_HD void tc_scaled_coords(float px, float py, float pz, double box, uint64_t X[3])
+{
+    const double m = 9223372036854775808.0; /* 2^63 */
+    double x = (double)px / box, y = (double)py / box, z = (double)pz / box;
+    X[0] = (uint64_t)(y * m);
+    X[1] = (uint64_t)(z * m);
+    X[2] = (uint64_t)(x * m);
+}
+
+/* Skilling's transpose <-> Hilbert transform, "inverse undo" + Gray encode
+ * (peano.c:140-177).  Works in place on the {y,z,x} transpose array. */
+TC_HD void tc_hilbert_transpose(uint64_t X[3])
+{
+    uint64_t X0 = X[0], X1 = X[1], X2 = X[2];
+    for (uint64_t q = 1ULL << 63; q > 1; q >>= 1) {
+        const uint64_t P = q - 1;
+        if (X0 & q) X0 ^= P;
+        if (X1 & q) {
+            X0 ^= P;
+        } else {
+            uint64_t t = (X0 ^ X1) & P;
+            X0 ^= t; X1 ^= t;
+        }
+        if (X2 & q) {
+            X0 ^= P;
+        } else {
+            uint64_t t = (X0 ^ X2) & P;
+            X0 ^= t; X2 ^= t;
+        }
+    }
+    X1 ^= X0;
+    X2 ^= X1;
+    uint64_t t = X2;
+    X2 ^= X2 >> 1; X2 ^= X2 >> 2; X2 ^= X2 >> 4; X2 ^= X2 >> 8; X2 ^= X2 >> 16; X2 ^= X2 >> 32;
+    t ^= X2;
+    X1 ^= t;
+    X0 ^= t;
+    X[0] = X0; X[1] = X1; X[2] = X2;
+}
+
+/* Spread the low 21 bits of v so that bit k lands at bit 3k. */
+TC_HD uint64_t tc_spread3(uint64_t v)
+{
+    v &= 0x1fffffULL;
+    v = (v | (v << 32)) & 0x001f00000000ffffULL;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffULL;
+    v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+    v = (v | (v << 2)) & 0x1249249249249249ULL;
+    return v;
+}
+
+/* 128-bit key of peano.c:181-200: triplets (X0,X1,X2) of bits 62..21, MSB first,
+ * occupying key bits 127..2 (the bit-63 triplet is shifted out, low 2 bits are 0).
+ * Written as two 21-triplet interleaves instead of the reference's 43-step loop. */
+TC_HD void tc_key_from_transpose(const uint64_t X[3], uint64_t *hi, uint64_t *lo)
+{
+    /* triplets for bits 62..42 -> 63 bits "a"; bits 41..21 -> 63 bits "b" */
+    uint64_t a = (tc_spread3(X[0] >> 42) << 2) | (tc_spread3(X[1] >> 42) << 1) | tc_spread3(X[2] >> 42);
+    uint64_t b = (tc_spread3(X[0] >> 21) << 2) | (tc_spread3(X[1] >> 21) << 1) | tc_spread3(X[2] >> 21);
+    /* key = (a << 65) | (b << 2) */
+    *hi = (a << 1) | (b >> 62);
+    *lo = b << 2;
+}
+
+TC_HD void tc_peano_key(float px, float py, float pz, double box, uint64_t *hi, uint64_t *lo)
+{
+    uint64_t X[3];
+    tc_scaled_coords(px, py, pz, box, X);
+    tc_hilbert_transpose(X);
+    tc_key_from_transpose(X, hi, lo);
+}
+
+/* Number of leading Hilbert levels (triplets, level 1 = bits 62 of X) two keys share.
+ * Keys are the 128-bit keys above; level l occupies key bits [128-3l, 128-3l+2]. */
+TC_HD int tc_common_levels(uint64_t ahi, uint64_t alo, uint64_t bhi, uint64_t blo)
+{
+    uint64_t xh = ahi ^ bhi, xl = alo ^ blo;
+    int lz;
+    if (xh) lz = __builtin_clzll(xh);
+    else if (xl) lz = 64 + __builtin_clzll(xl);
+    else return TC_NTRIPLETS;
+    return lz / 3;
+}
+
+/* ------------------------------------------------------------------ SPH kernels */
+
+/* sph.c:426-432: Wendland C6 with 1/h^3; args are f32, u=r/h is an f32 divide,
+ * the polynomial runs in f64 left to right, the result is rounded to f32.
+ * `norm_h3` must be  TC_WC6_NORM / (double)(h*h*h)  with h*h*h evaluated in f32. */
+TC_HD float tc_wc6(float r, float h, double norm_h3)
+{
+    const double u = r / h;
+    const double t = 1 - u;
+    return (float)(norm_h3 * t * t * t * t * t * t * t * t * (1 + 8 * u + 25 * u * u + 32 * u * u * u));
+}
+
+/* sph.c:434-440: derivative; u stays f32, t=(double)(1-u) with the subtraction in f32,
+ * the trailing polynomial (16u^2+7u+1) is evaluated in f32.
+ * `norm_h4m22` must be  TC_WC6_NORM / (double)(h*h*h*h) * -22.0 . */
+TC_HD float tc_dwc6(float r, float h, double norm_h4m22)
+{
+    const float u = r / h;
+    const double t = 1 - u;
+    return (float)(norm_h4m22 * t * t * t * t * t * t * t * u * (16 * u * u + 7 * u + 1));
+}
+
+/* wvt_relax.c:275-281: un-normalised WC6 used by the WVT sweep (returns double) */
+TC_HD double tc_wvt_wc6(float r, float h)
+{
+    const double u = r / h;
+    const double t = 1 - u;
+    return TC_WC6_NORM * t * t * t * t * t * t * t * t * (1 + 8 * u + 25 * u * u + 32 * u * u * u);
+}
+
+/* ------------------------------------------------------------------ density model */
+
+typedef struct {
+    double cx, cy, cz;   /* D_CoM + boxhalf is NOT pre-added: see tc_density_model */
+    double rho0, beta, rcore, rcut;
+    double mass_gas;
+} tc_halo_dev;
+
+/* setup.c:598-615 (Makefile default: no DOUBLE_BETA_COOL_CORES) */
+TC_HD double tc_gas_density_profile(double r, double rho0, double beta, double rc, double rcut)
+{
+    return rho0 * pow(1 + (r / rc) * (r / rc), -3.0 / 2.0 * beta)
+           / (1 + ((r / rcut) * (r / rcut) * (r / rcut)) * (r / rcut));
+}
+
+/* wvt_relax.c:227-256 */
+TC_HD float tc_density_model(float px, float py, float pz, double boxhalf, const tc_halo_dev *halo, int nhalos)
+{
+    const double x = px, y = py, z = pz;
+    double rho = 0;
+    for (int i = 0; i < nhalos; i++) {
+        if (halo[i].mass_gas == 0) continue;
+        double dx = x - halo[i].cx - boxhalf;
+        double dy = y - halo[i].cy - boxhalf;
+        double dz = z - halo[i].cz - boxhalf;
+        double r2 = dx * dx + dy * dy + dz * dz;
+        double rho_i = tc_gas_density_profile(sqrt(r2), halo[i].rho0, halo[i].beta, halo[i].rcore, halo[i].rcut);
+        rho = fmax(rho_i, rho);
+    }
+    return (float)rho;
+}
+
+/* ------------------------------------------------------------------ ball-query predicate */
+
+/* tree.c:67-89: f32, |d| folded at box/2, strict <.  Returns r2 (f32). */
+TC_HD float tc_ngb_r2(float xi, float yi, float zi, float xj, float yj, float zj, float boxhalf, float boxsize)
+{
+    float dx = fabsf(xi - xj), dy = fabsf(yi - yj), dz = fabsf(zi - zj);
+    if (dx > boxhalf) dx -= boxsize;
+    if (dy > boxhalf) dy -= boxsize;
+    if (dz > boxhalf) dz -= boxsize;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+/* sph.c:111-138: f64 separation with +-box/2 folding, returns r = sqrt(r2) */
+TC_HD double tc_pair_r(float xi, float yi, float zi, float xj, float yj, float zj, double boxhalf, double boxsize)
+{
+    double dx = (double)xi - (double)xj, dy = (double)yi - (double)yj, dz = (double)zi - (double)zj;
+    if (dx > boxhalf) dx -= boxsize;
+    if (dx < -boxhalf) dx += boxsize;
+    if (dy > boxhalf) dy -= boxsize;
+    if (dy < -boxhalf) dy += boxsize;
+    if (dz > boxhalf) dz -= boxsize;
+    if (dz < -boxhalf) dz += boxsize;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+#endif /* TC_MATH_H */
