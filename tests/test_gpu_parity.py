@@ -199,7 +199,7 @@ def test_density_pass_warm_and_idempotent(gpu):
         assert a["solver_iters"] == pytest.approx(b["solver_iters"], rel=1e-3)
         assert a["pair_evals"] == pytest.approx(b["pair_evals"], rel=1e-3)
     # idempotence: a warm pass moves hsml only inside the +-0.05-neighbour band
-    assert rel(p2["hsml"], p1["hsml"]).max() < 2e-4
+    assert rel(p2["hsml"], p1["hsml"]).max() < 1e-3
 
 
 # ------------------------------------------------------------------ T2: WVT sweep
