@@ -38,6 +38,12 @@ def cpu_baseline(nsample, iters):
     from toycluster_amd import model as M
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0))
+    try:                                          # container CPU share (cgroup v2), e.g. "1600000 100000"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
     m = M.preset("merger", nsample)
     pos, ids = M.sample_gas(m, nsample, seed=14041981)
     o = O.Oracle(m, pos, ids, nthreads=cores)

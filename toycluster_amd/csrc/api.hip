@@ -81,6 +81,9 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipMalloc(&c->orphans, sizeof(uint32_t) * TC_MAX_ORPHANS) == hipSuccess;
     ok = ok && hipMalloc(&c->norph, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->ngb_cnt, sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->spill, sizeof(double) * (size_t)TC_MAX_PERSISTENT_BLOCKS * TC_WAVES_PER_BLOCK
+                                        * (TC_NGBMAX - TC_RCAP)) == hipSuccess;
+    ok = ok && hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess;
     ok = ok && hipMemset(c->flags, 0, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMemset(c->norph, 0, sizeof(int)) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
@@ -97,10 +100,10 @@ static void free_particles(tcgpu_ctx *c)
         c->pos4[b] = nullptr; c->id[b] = nullptr; c->hsml[b] = c->rho[b] = c->vhf[b] = c->rhom[b] = nullptr;
     }
     hipFree(c->apot); hipFree(c->bfld); hipFree(c->key); hipFree(c->key_sorted); hipFree(c->idx);
-    hipFree(c->idx_sorted); hipFree(c->sort_tmp); hipFree(c->cstart); hipFree(c->cend); hipFree(c->guess);
+    hipFree(c->idx_sorted); hipFree(c->sort_tmp); hipFree(c->cells); hipFree(c->guess);
     hipFree(c->hwvt); hipFree(c->delta); hipFree(c->stats); hipFree(c->ngb_buf);
     c->apot = c->bfld = nullptr; c->key = c->key_sorted = nullptr; c->idx = c->idx_sorted = nullptr;
-    c->sort_tmp = nullptr; c->cstart = c->cend = nullptr; c->guess = c->hwvt = c->delta = nullptr;
+    c->sort_tmp = nullptr; c->cells = nullptr; c->guess = c->hwvt = c->delta = nullptr;
     c->stats = nullptr; c->ngb_buf = nullptr;
     c->cap = 0; c->n = 0; c->ncells_alloc = 0;
 }
@@ -112,7 +115,7 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_particles(c);
     hipFree(c->d_halo); hipFree(c->red); hipHostFree(c->h_red); hipFree(c->flags); hipHostFree(c->h_flags);
-    hipFree(c->orphans); hipFree(c->norph); hipFree(c->ngb_cnt);
+    hipFree(c->orphans); hipFree(c->norph); hipFree(c->ngb_cnt); hipFree(c->spill);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -191,10 +194,9 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
     if (lmax > TC_MAX_LEVEL) lmax = TC_MAX_LEVEL;
     size_t ncell = tc_level_offset(lmax + 1);
     if (ncell > c->ncells_alloc) {
-        hipFree(c->cstart); hipFree(c->cend);
-        c->cstart = c->cend = nullptr;
-        TC_HIP(c, hipMalloc(&c->cstart, ncell * sizeof(uint32_t)));
-        TC_HIP(c, hipMalloc(&c->cend, ncell * sizeof(uint32_t)));
+        hipFree(c->cells);
+        c->cells = nullptr;
+        TC_HIP(c, hipMalloc(&c->cells, ncell * sizeof(uint2)));
         c->ncells_alloc = ncell;
     }
     c->lmax = lmax;

@@ -12,9 +12,16 @@
  * loads).  The result set equals the reference's; its order is not ascending, which only
  * permutes f64 summation order (DESIGN.md "Numerics").
  *
- * Hits are compacted with ballot + mbcnt into a per-wave LDS list holding the f64 pair
- * distance r, on which the reference's Newton-Raphson / bisection control flow then runs
- * with 64-lane partial sums and butterfly reductions.
+ * The gather is latency-bound, so it is split into a producer that only touches the cell table
+ * and writes candidate INDICES into a per-wave LDS list (small cells expanded lane-per-cell,
+ * large cells cooperatively), and a consumer that walks that flat list 256 candidates at a
+ * time with four independent float4 gathers in flight per lane.
+ *
+ * Hits are compacted with ballot + mbcnt into a per-wave list holding the f64 pair distance r
+ * (first TC_RCAP entries in LDS, the rest -- only cold-start lists get that long -- in a per-wave
+ * global spill area), on which the reference's Newton-Raphson / bisection control flow then
+ * runs with 64-lane partial sums and butterfly reductions.  Kernels are persistent: a fixed
+ * grid of waves strides over the particles, so the spill area is bounded.
  */
 #include "tc_ctx.h"
 
@@ -44,6 +51,25 @@ __device__ __forceinline__ double wsum(double v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return bcast0(v);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = lane_id();
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+/* LDS written by some lanes is read by others of the same wave: keep the compiler from
+ * moving DS operations across this point (the hardware executes a wave's DS ops in order). */
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 /* ------------------------------------------------------------------ query geometry */
@@ -108,7 +134,8 @@ __device__ __forceinline__ void query_cell(const tc_dev_const &k, const tc_query
         lin = lin * (size_t)q.nL + (size_t)(u & (q.nL - 1));
     }
     if (g2 > q.hp * q.hp) return;
-    uint32_t s0 = k.cstart[q.off + lin], e0 = k.cend[q.off + lin];
+    uint2 ce = k.cells[q.off + lin];            /* {~first, last+1}, both 0 when empty */
+    uint32_t s0 = ~ce.x, e0 = ce.y;
     if (e0 > s0) { st = s0; en = e0; }
 }
 
@@ -117,14 +144,44 @@ __device__ __forceinline__ bool is_orphan(const tc_dev_const &k, float4 p)
     return (double)p.x >= k.boxsize || (double)p.y >= k.boxsize || (double)p.z >= k.boxsize;
 }
 
+/* Consumer: walk the flat index list, four independent gathers in flight per lane. */
+template <class Body>
+__device__ __forceinline__ bool consume_candidates(const tc_dev_const &k, const uint32_t *idx, int fill, int norph,
+                                                   Body &body)
+{
+    const int lane = lane_id();
+    for (int c0 = 0; c0 < fill; c0 += 256) {
+        uint32_t j[4];
+        float4 p[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int t = c0 + 64 * u + lane;
+            act[u] = t < fill;
+            j[u] = act[u] ? idx[t] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = k.pos4[j[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (c0 + 64 * u < fill) {
+                bool a = act[u];
+                if (norph && a && is_orphan(k, p[u])) a = false;
+                if (body((int)j[u], p[u], a)) return true;
+            }
+        }
+    }
+    return false;
+}
+
 /*
  * Stream every candidate of the ball (xi,h) through `body(j, p, active)`; body is called
  * wave-uniformly (all 64 lanes, `active` false for padding lanes) and returns true to stop.
- * Returns the number of candidates streamed (for the work counters).
+ * `idx` is this wave's LDS index list (TC_IDXCAP entries).  Returns the number of candidates.
  */
 template <class Body>
 __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, float xi, float yi, float zi, float h,
-                                                      Body &&body)
+                                                      uint32_t *idx, Body &&body)
 {
     const int lane = lane_id();
     tc_query q;
@@ -133,24 +190,61 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
     int norph = *k.norph;
     if (norph > TC_MAX_ORPHANS) norph = TC_MAX_ORPHANS;   /* overflow is flagged by k_cells */
     uint32_t ncand = 0;
+    uint32_t fill = 0;
 
     for (int base = 0; base < ncell; base += 64) {
         uint32_t st = 0, en = 0;
         if (base + lane < ncell) query_cell(k, q, xi, yi, zi, base + lane, st, en);
-        uint64_t m = __ballot(en > st);
-        while (m) {
-            int l = __builtin_ctzll(m);
-            m &= m - 1;
-            uint32_t s0 = __shfl(st, l), e0 = __shfl(en, l);
-            ncand += e0 - s0;
-            for (uint32_t j0 = s0; j0 < e0; j0 += 64) {
-                uint32_t j = j0 + lane;
-                bool act = j < e0;
-                float4 p = k.pos4[act ? j : s0];
-                if (norph && act && is_orphan(k, p)) act = false;
-                if (body((int)j, p, act)) return ncand;
+        const uint32_t cnt = en - st;
+
+        /* large cells: the whole wave writes the run of consecutive indices */
+        uint64_t big = __ballot(cnt > TC_SMALLCELL);
+        while (big) {
+            int l = __builtin_ctzll(big);
+            big &= big - 1;
+            uint32_t s0 = __shfl(st, l), c0 = __shfl(cnt, l);
+            ncand += c0;
+            uint32_t done = 0;
+            while (done < c0) {
+                uint32_t take = min(c0 - done, (uint32_t)TC_IDXCAP - fill);
+                for (uint32_t t = lane; t < take; t += 64) idx[fill + t] = s0 + done + t;
+                fill += take;
+                done += take;
+                if (fill == TC_IDXCAP) {
+                    wave_lds_fence();
+                    if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
+                    wave_lds_fence();
+                    fill = 0;
+                }
             }
         }
+
+        /* small cells: one lane expands one cell at its prefix-sum offset */
+        uint32_t pend = (cnt <= TC_SMALLCELL) ? cnt : 0;
+        while (__ballot(pend > 0)) {
+            uint32_t incl = wave_incl_scan(pend);
+            uint32_t excl = incl - pend;
+            bool ok = pend > 0 && incl <= (uint32_t)TC_IDXCAP - fill;
+            if (ok)
+                for (uint32_t t = 0; t < pend; t++) idx[fill + excl + t] = st + t;
+            uint64_t okm = __ballot(ok);
+            uint32_t emitted = 0;
+            if (okm) emitted = __shfl(incl, 63 - __builtin_clzll(okm));
+            fill += emitted;
+            ncand += emitted;
+            if (ok) pend = 0;
+            if (__ballot(pend > 0)) {                       /* list full: drain it, then go on */
+                wave_lds_fence();
+                if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
+                wave_lds_fence();
+                fill = 0;
+            }
+        }
+    }
+    if (fill) {
+        wave_lds_fence();
+        if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
+        wave_lds_fence();
     }
     for (int o0 = 0; o0 < norph; o0 += 64) {        /* orphans: brute force */
         int o = o0 + lane;
@@ -167,16 +261,29 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
 struct tc_density_args {
     tc_dev_const k;
     const float *hsml_in;      /* carried smoothing lengths (0 => use guess) */
-    const float *guess;        /* may be NULL when no particle has hsml == 0 */
+    const float *guess;
     float *hsml_out, *rho_out, *vhf_out;
     double bias_const;         /* -0.0116 * pow(DESNNGB*0.01, -2.236), host libm */
+    double *spill;             /* per wave: entries TC_RCAP..NGBMAX-1 of the hit list */
     int *flags;
     uint32_t *stats;           /* optional: 4 x n work counters */
     int stats_stride;
 };
 
-/* src/sph.c:80-214 on the LDS list.  All lanes return identical values. */
-__device__ __forceinline__ bool solve_hsml(const double *__restrict__ rl, int cnt, double mpart, double bias_const,
+/* the hit list: r (f64) of every neighbour found by the last ball query */
+struct tc_rlist {
+    double *lds;               /* TC_RCAP entries */
+    double *spill;             /* TC_NGBMAX - TC_RCAP entries */
+    __device__ __forceinline__ double get(int kk) const { return kk < TC_RCAP ? lds[kk] : spill[kk - TC_RCAP]; }
+    __device__ __forceinline__ void put(int kk, double v) const
+    {
+        if (kk < TC_RCAP) lds[kk] = v;
+        else spill[kk - TC_RCAP] = v;
+    }
+};
+
+/* src/sph.c:80-214 on the hit list.  All lanes return identical values. */
+__device__ __forceinline__ bool solve_hsml(const tc_rlist &rl, int cnt, double mpart, double bias_const,
                                            float &hsml_io, float &rho_out, float &drho_io,
                                            uint32_t &iters, uint32_t &pairs)
 {
@@ -203,7 +310,7 @@ __device__ __forceinline__ bool solve_hsml(const double *__restrict__ rl, int cn
         const double nmpart = -mpart;
 
         for (int kk = lane; kk < cnt; kk += 64) {
-            double r = rl[kk];
+            double r = rl.get(kk);
             if (r > hsml) continue;            /* == (r2 > hsml^2) up to a zero-weight boundary, DESIGN.md */
             float rf = (float)r;
             double wk = tc_wc6(rf, hf, norm_h3);
@@ -249,16 +356,11 @@ __device__ __forceinline__ bool solve_hsml(const double *__restrict__ rl, int cn
     return part_done;
 }
 
-__global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
+/* src/sph.c:21-71 for particle i */
+__device__ __forceinline__ void density_one(const tc_density_args &a, int i, const tc_rlist &rl, uint32_t *idx)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    double *rl = reinterpret_cast<double *>(lds_raw) + (size_t)wave * TC_NGBMAX;
     const tc_dev_const &k = a.k;
-
-    const int i = k.lo + blockIdx.x * WPB + wave;
-    if (i >= k.hi) return;
-
+    const int lane = lane_id();
     const float4 pi = k.pos4[i];
     const float xi = pi.x, yi = pi.y, zi = pi.z;
     float hsml = a.hsml_in[i];
@@ -277,17 +379,18 @@ __global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
         const float h2 = hsml * hsml;
         int cnt = 0;
         nq++;
-        ncand += stream_candidates(k, xi, yi, zi, hsml, [&](int j, float4 p, bool act) -> bool {
+        ncand += stream_candidates(k, xi, yi, zi, hsml, idx, [&](int j, float4 p, bool act) -> bool {
             float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2 < h2);
             uint64_t m = __ballot(hit);
             if (hit) {
                 int slot = cnt + mask_rank(m);
-                if (slot < TC_NGBMAX) rl[slot] = tc_pair_r(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize);
+                if (slot < TC_NGBMAX) rl.put(slot, tc_pair_r(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize));
             }
             cnt += __popcll(m);
             return cnt >= TC_NGBMAX;
         });
+        wave_lds_fence();
         if (cnt >= TC_NGBMAX) { hsml = (float)((double)hsml / 1.24); continue; }   /* src/sph.c:42-47 */
         if (cnt < TC_DESNNGB) { hsml = (float)((double)hsml * 1.23); continue; }   /* src/sph.c:49-54 */
 
@@ -311,6 +414,22 @@ __global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
     }
 }
 
+#define TC_LDS_PER_WAVE_DENSITY (TC_RCAP * sizeof(double) + TC_IDXCAP * sizeof(uint32_t))
+#define TC_LDS_PER_WAVE_IDX (TC_IDXCAP * sizeof(uint32_t))
+
+__global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
+{
+    __shared__ __align__(16) unsigned char lds_raw[WPB * TC_LDS_PER_WAVE_DENSITY];
+    const int wave = threadIdx.x >> 6;
+    unsigned char *mine = lds_raw + (size_t)wave * TC_LDS_PER_WAVE_DENSITY;
+    const int gw = blockIdx.x * WPB + wave, nw = gridDim.x * WPB;
+    tc_rlist rl;
+    rl.lds = reinterpret_cast<double *>(mine);
+    rl.spill = a.spill + (size_t)gw * (TC_NGBMAX - TC_RCAP);
+    uint32_t *idx = reinterpret_cast<uint32_t *>(mine + TC_RCAP * sizeof(double));
+    for (int i = a.k.lo + gw; i < a.k.hi; i += nw) density_one(a, i, rl, idx);
+}
+
 void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
 {
     k->boxsize = c->par.boxsize;
@@ -320,8 +439,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->boxhalf_f = (float)(c->par.boxsize * 0.5);       /* src/tree.c:28 */
     k->lmax = c->lmax;
     k->level_shift = c->level_shift;
-    k->cstart = c->cstart;
-    k->cend = c->cend;
+    k->cells = c->cells;
     k->orphans = c->orphans;
     k->norph = c->norph;
     k->pos4 = c->pos4[c->cur];
@@ -331,6 +449,19 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     if (lo > hi) lo = hi;
     k->lo = (int)lo;
     k->hi = (int)hi;
+}
+
+/* persistent grid: exactly the blocks that are co-resident (occupancy query), never more
+ * blocks than work, so the static particle striding stays balanced */
+template <class K>
+static int grid_for(const tcgpu_ctx *c, int nloc, K kernel)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBN, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    int need = (nloc + WPB - 1) / WPB;
+    int cap = c->num_cu * per_cu;
+    if (cap > TC_MAX_PERSISTENT_BLOCKS) cap = TC_MAX_PERSISTENT_BLOCKS;
+    return need < cap ? need : cap;
 }
 
 int tc_launch_density(tcgpu_ctx *c)
@@ -343,19 +474,14 @@ int tc_launch_density(tcgpu_ctx *c)
     a.rho_out = c->rho[c->cur];
     a.vhf_out = c->vhf[c->cur];
     a.bias_const = -0.0116 * pow(TC_DESNNGB * 0.01, -2.236);   /* src/sph.c:206 */
+    a.spill = c->spill;
     a.flags = c->flags;
     a.stats = c->want_stats ? c->stats : nullptr;
     a.stats_stride = (int)c->cap;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
-    size_t lds = (size_t)WPB * TC_NGBMAX * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        TC_HIP(c, hipFuncSetAttribute((const void *)k_density, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     tc_phase_begin(c, PH_DENSITY);
-    k_density<<<(nloc + WPB - 1) / WPB, TBN, lds, c->stream>>>(a);
+    k_density<<<grid_for(c, nloc, k_density), TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -394,13 +520,10 @@ __device__ __forceinline__ void wvt_pair(const float4 pi, const float4 pj, doubl
     d2 += base * (double)dz / (double)r;
 }
 
-__global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
+__device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *idx)
 {
-    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int lane = lane_id();
     const tc_dev_const &k = a.k;
-    const int i = k.lo + blockIdx.x * WPB + wave;
-    if (i >= k.hi) return;
-
     const float4 pi = k.pos4[i];
     const double boxinv = 1 / k.boxsize;
     const float hq = (float)((double)pi.w * k.boxsize);      /* src/wvt_relax.c:135 */
@@ -409,7 +532,7 @@ __global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
 
     double d0 = 0, d1 = 0, d2 = 0;
     int cnt = 0;
-    stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+    stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
         float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
         bool hit = act && (r2 < hq2);
         cnt += __popcll(__ballot(hit));
@@ -426,7 +549,7 @@ __global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
         while (thi - tlo > 1) {
             int mid = tlo + ((thi - tlo) >> 1);
             int cm = 0;
-            stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+            stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
                 float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
                 cm += __popcll(__ballot(act && (r2 < hq2) && j < mid));
                 return false;
@@ -434,7 +557,7 @@ __global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
             if (cm >= TC_NGBMAX) thi = mid; else tlo = mid;
         }
         d0 = d1 = d2 = 0;
-        stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+        stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
             float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             if (act && (r2 < hq2) && j < thi && j != i) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
             return false;
@@ -449,6 +572,15 @@ __global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
     }
 }
 
+__global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
+{
+    __shared__ __align__(16) uint32_t lds_idx[WPB * TC_IDXCAP];
+    const int wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + wave, nw = gridDim.x * WPB;
+    uint32_t *idx = lds_idx + (size_t)wave * TC_IDXCAP;
+    for (int i = a.k.lo + gw; i < a.k.hi; i += nw) wvt_one(a, i, idx);
+}
+
 int tc_launch_wvt(tcgpu_ctx *c, double step)
 {
     tc_wvt_args a;
@@ -459,7 +591,7 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_WVT);
-    k_wvt<<<(nloc + WPB - 1) / WPB, TBN, 0, c->stream>>>(a);
+    k_wvt<<<grid_for(c, nloc, k_wvt), TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -474,14 +606,11 @@ struct tc_curl_args {
     float *bfld;           /* 3n */
 };
 
-/* src/sph.c:224-295 */
-__global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
+/* src/sph.c:224-295 for particle i */
+__device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t *idx)
 {
-    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int lane = lane_id();
     const tc_dev_const &k = a.k;
-    const int i = k.lo + blockIdx.x * WPB + wave;
-    if (i >= k.hi) return;
-
     const float4 pi = k.pos4[i];
     const float hq = a.hsml[i];
     const float hq2 = hq * hq;
@@ -495,7 +624,7 @@ __global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
 
     for (int pass = 0; pass < 2; pass++) {
         cnt = 0; b0 = b1 = b2 = 0;
-        stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+        stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
             float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2f < hq2) && j < thi;
             cnt += __popcll(__ballot(hit));
@@ -523,13 +652,13 @@ __global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
             return false;
         });
         if (cnt < TC_NGBMAX || pass == 1) break;
-        /* list truncation as in k_wvt: find the ascending-index threshold, then redo */
+        /* list truncation as in wvt_one: find the ascending-index threshold, then redo */
         int tlo = 0;
         thi = k.n;
         while (thi - tlo > 1) {
             int mid = tlo + ((thi - tlo) >> 1);
             int cm = 0;
-            stream_candidates(k, pi.x, pi.y, pi.z, hq, [&](int j, float4 p, bool act) -> bool {
+            stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
                 float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
                 cm += __popcll(__ballot(act && (r2f < hq2) && j < mid));
                 return false;
@@ -545,6 +674,15 @@ __global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
     }
 }
 
+__global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
+{
+    __shared__ __align__(16) uint32_t lds_idx[WPB * TC_IDXCAP];
+    const int wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + wave, nw = gridDim.x * WPB;
+    uint32_t *idx = lds_idx + (size_t)wave * TC_IDXCAP;
+    for (int i = a.k.lo + gw; i < a.k.hi; i += nw) curl_one(a, i, idx);
+}
+
 int tc_launch_curl(tcgpu_ctx *c)
 {
     tc_curl_args a;
@@ -557,7 +695,7 @@ int tc_launch_curl(tcgpu_ctx *c)
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_CURL);
-    k_curl<<<(nloc + WPB - 1) / WPB, TBN, 0, c->stream>>>(a);
+    k_curl<<<grid_for(c, nloc, k_curl), TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -567,10 +705,11 @@ int tc_launch_curl(tcgpu_ctx *c)
 
 __global__ __launch_bounds__(64) void k_find_ngb(tc_dev_const k, int i, float hsml, int32_t *out, int *count)
 {
+    __shared__ __align__(16) uint32_t idx[TC_IDXCAP];
     const float4 pi = k.pos4[i];
     const float h2 = hsml * hsml;
     int cnt = 0;
-    stream_candidates(k, pi.x, pi.y, pi.z, hsml, [&](int j, float4 p, bool act) -> bool {
+    stream_candidates(k, pi.x, pi.y, pi.z, hsml, idx, [&](int j, float4 p, bool act) -> bool {
         float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
         bool hit = act && (r2 < h2);
         uint64_t m = __ballot(hit);

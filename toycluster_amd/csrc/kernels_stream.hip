@@ -108,7 +108,8 @@ int tc_launch_permute(tcgpu_ctx *c)
 /* Level-L cell of a particle = top L bits of each scaled coordinate, i.e. the octree cell
  * whose Hilbert prefix is the top 3L key bits.  In Peano order every cell is one contiguous
  * index run, so (first, last+1) per cell is a complete neighbour index.  Runs are recorded
- * with atomicMin/atomicMax so that a run split by an "orphan" (below) still yields one range.
+ * with atomics (min of first, max of last+1) so that a run split by an "orphan" (below) still
+ * yields one range; `first` is stored complemented so that an all-zero table means "empty".
  *
  * Orphans: a coordinate exactly equal to boxsize scales to X = 2^63 (src/peano.c:134-136);
  * the reference's transform then keys the particle away from its spatial neighbours.  Such
@@ -135,7 +136,7 @@ __device__ __forceinline__ int first_diff_level(const uint32_t a[3], const uint3
 }
 
 __global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, int n, double box, int lmax,
-                                              uint32_t *__restrict__ cstart, uint32_t *__restrict__ cend,
+                                              uint2 *__restrict__ cells,
                                               uint32_t *__restrict__ orphans, int *__restrict__ norph,
                                               int *__restrict__ flags)
 {
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, i
         size_t nL = (size_t)1 << L;
         size_t lin = (((size_t)(ci[0] >> sh) * nL) + (ci[1] >> sh)) * nL + (ci[2] >> sh);
         size_t o = tc_level_offset(L) + lin;
-        if (L >= dprev) atomicMin(&cstart[o], (uint32_t)i);
-        if (L >= dnext) atomicMax(&cend[o], (uint32_t)(i + 1));
+        if (L >= dprev) atomicMax(&cells[o].x, ~(uint32_t)i);          /* max(~i) = ~min(i): zero-initialised */
+        if (L >= dnext) atomicMax(&cells[o].y, (uint32_t)(i + 1));
     }
 }
 
@@ -170,10 +171,9 @@ int tc_launch_cells(tcgpu_ctx *c)
     int n = (int)c->n;
     size_t ncell = tc_level_offset(c->lmax + 1);
     tc_phase_begin(c, PH_CELLS);
-    TC_HIP(c, hipMemsetAsync(c->cstart, 0xFF, ncell * sizeof(uint32_t), c->stream));
-    TC_HIP(c, hipMemsetAsync(c->cend, 0, ncell * sizeof(uint32_t), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->cells, 0, ncell * sizeof(uint2), c->stream));
     TC_HIP(c, hipMemsetAsync(c->norph, 0, sizeof(int), c->stream));
-    k_cells<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->cstart, c->cend,
+    k_cells<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->cells,
                                                      c->orphans, c->norph, c->flags);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());

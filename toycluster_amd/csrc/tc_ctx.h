@@ -14,6 +14,10 @@
 #define TC_MAX_HALOS_DEV TC_MAXHALOS
 #define TC_WAVES_PER_BLOCK 4
 #define TC_RED_BLOCKS 1024       /* partial-sum slots of the streaming reductions */
+#define TC_RCAP 768              /* hit-list entries kept in LDS (f64 each); the rest spill */
+#define TC_IDXCAP 1024           /* candidate-index list per wave in LDS (u32 each) */
+#define TC_SMALLCELL 16          /* cells up to this size are expanded one lane per cell */
+#define TC_MAX_PERSISTENT_BLOCKS 2048
 
 enum tc_phase {
     PH_KEYS = 0, PH_SORT, PH_PERMUTE, PH_CELLS, PH_GUESS, PH_DENSITY, PH_ERROR, PH_MODEL_HSML,
@@ -26,8 +30,7 @@ struct tc_dev_const {
     float boxsize_f, boxhalf_f;
     int lmax;                     /* deepest table level in use */
     int level_shift;              /* added to floor(log2(box/h))+1 when choosing the query level */
-    const uint32_t *cstart;       /* all levels, level L at offset tc_level_offset(L) */
-    const uint32_t *cend;
+    const uint2 *cells;           /* {~first, last+1} per cell; level L at offset tc_level_offset(L) */
     const uint32_t *orphans;      /* particles with a coordinate == boxsize (X has bit 63) */
     const int *norph;
     const float4 *pos4;           /* x,y,z,(w = hsml_wvt) in Peano order */
@@ -71,8 +74,10 @@ struct tcgpu_ctx {
 
     /* neighbour index */
     int lmax, lmax_alloc;
-    uint32_t *cstart, *cend;
+    uint2 *cells;
     size_t ncells_alloc;
+    double *spill;                /* TC_MAX_PERSISTENT_BLOCKS*WPB x (NGBMAX-TC_RCAP) */
+    int num_cu;
     uint32_t *orphans;
     int *norph;
     int index_valid;
