@@ -681,6 +681,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     if (!strcmp(name, "stats")) c->want_stats = value != 0;
     else if (!strcmp(name, "timing")) c->timing = value != 0;
     else if (!strcmp(name, "level_shift")) c->level_shift = (int)value;
+    else if (!strcmp(name, "ablate")) c->ablate = (int)value;
     else if (!strcmp(name, "lmax")) {
         if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "lmax must be set before tcgpu_upload_particles");
         c->lmax_override = (int)value;

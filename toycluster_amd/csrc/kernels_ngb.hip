@@ -32,6 +32,10 @@
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+/* mark a value the program knows to be wave-uniform as such (keeps it in SGPRs, scalar branches) */
+__device__ __forceinline__ int U(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t U(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 __device__ __forceinline__ int mask_rank(uint64_t m) /* set bits below this lane */
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -46,21 +50,40 @@ __device__ __forceinline__ double bcast0(double v)
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
-/* butterfly sum: every lane ends with the same bits (IEEE add is commutative) */
+/* one DPP step of a 64-bit value: lanes without a source (or rows masked out) receive +0.0 */
+#define TC_DPP_F64(v, ctrl, rowmask)                                                                         \
+    __builtin_bit_cast(double,                                                                               \
+        ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(__builtin_bit_cast(uint64_t, v) >> 32), \
+                                                         ctrl, rowmask, 0xf, false) << 32)                  \
+        | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)__builtin_bit_cast(uint64_t, v), ctrl, rowmask, 0xf, false))
+
+/* wave sum in registers (DPP row shifts + row broadcasts); the total lands in lane 63 and is
+ * returned wave-uniform.  Fixed summation tree => bitwise reproducible run to run. */
 __device__ __forceinline__ double wsum(double v)
 {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return bcast0(v);
+    v += TC_DPP_F64(v, 0x111, 0xf);   /* row_shr:1 */
+    v += TC_DPP_F64(v, 0x112, 0xf);   /* row_shr:2 */
+    v += TC_DPP_F64(v, 0x114, 0xf);   /* row_shr:4 */
+    v += TC_DPP_F64(v, 0x118, 0xf);   /* row_shr:8 */
+    v += TC_DPP_F64(v, 0x142, 0xa);   /* row_bcast:15 */
+    v += TC_DPP_F64(v, 0x143, 0xc);   /* row_bcast:31 */
+    uint64_t u = __builtin_bit_cast(uint64_t, v);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+/* inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (no LDS traffic) */
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    const int lane = lane_id();
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   /* row_shr:1 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   /* row_shr:2 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   /* row_shr:4 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   /* row_shr:8 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1,3 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2,3 */
+    return (uint32_t)x;
 }
 
 /* LDS written by some lanes is read by others of the same wave: keep the compiler from
@@ -93,6 +116,7 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
     q.L = L;
     q.nL = 1 << L;
     q.s = k.boxsize / (double)q.nL;
+    const double inv_s = (double)q.nL / k.boxsize;
     q.off = tc_level_offset(L);
     /* pad: the f32 predicate can accept pairs a few ulp beyond h */
     q.hp = (double)h * (1.0 + 1e-5) + k.boxsize * 1e-7;
@@ -101,8 +125,8 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
     for (int d = 0; d < 3; d++) {
         int lo = 0, nd = q.nL;
         if (!huge) {
-            lo = (int)floor(((double)xs[d] - q.hp) / q.s);
-            int hi = (int)floor(((double)xs[d] + q.hp) / q.s);
+            lo = (int)floor(((double)xs[d] - q.hp) * inv_s);     /* margins in hp absorb the rounding */
+            int hi = (int)floor(((double)xs[d] + q.hp) * inv_s);
             nd = hi - lo + 1;
         }
         q.full[d] = false;
@@ -150,6 +174,7 @@ __device__ __forceinline__ bool consume_candidates(const tc_dev_const &k, const 
                                                    Body &body)
 {
     const int lane = lane_id();
+    if (k.ablate == 1) return false;
     for (int c0 = 0; c0 < fill; c0 += 256) {
         uint32_t j[4];
         float4 p[4];
@@ -202,7 +227,8 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
         while (big) {
             int l = __builtin_ctzll(big);
             big &= big - 1;
-            uint32_t s0 = __shfl(st, l), c0 = __shfl(cnt, l);
+            uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)st, l);
+            uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, l);
             ncand += c0;
             uint32_t done = 0;
             while (done < c0) {
@@ -229,7 +255,7 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
                 for (uint32_t t = 0; t < pend; t++) idx[fill + excl + t] = st + t;
             uint64_t okm = __ballot(ok);
             uint32_t emitted = 0;
-            if (okm) emitted = __shfl(incl, 63 - __builtin_clzll(okm));
+            if (okm) emitted = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63 - __builtin_clzll(okm));
             fill += emitted;
             ncand += emitted;
             if (ok) pend = 0;
@@ -282,6 +308,18 @@ struct tc_rlist {
     }
 };
 
+/* ring of staged hit positions (and hsml_wvt for the sweep), TC_STAGE entries per wave */
+struct tc_stage {
+    float *x, *y, *z, *w;
+};
+
+/* src/sph.c:186-195, the rare bisection update (cold starts only); kept out of line so that the
+ * f64 pow() is not speculated into every Newton iteration */
+__device__ __attribute__((noinline)) double bisect_hsml(double lower, double upper)
+{
+    return pow(0.5 * ((lower * lower * lower) + (upper * upper * upper)), 1.0 / 3.0);
+}
+
 /* src/sph.c:80-214 on the hit list.  All lanes return identical values. */
 __device__ __forceinline__ bool solve_hsml(const tc_rlist &rl, int cnt, double mpart, double bias_const,
                                            float &hsml_io, float &rho_out, float &drho_io,
@@ -307,18 +345,46 @@ __device__ __forceinline__ bool solve_hsml(const tc_rlist &rl, int cnt, double m
         const double norm_h4 = TC_WC6_NORM / (double)(hf * hf * hf * hf) * -22.0;
         const double h3 = hsml * hsml * hsml;
         const double three_h = 3 / hsml;
+        const double inv_h = 1 / hsml;
         const double nmpart = -mpart;
+        const double fpt_h3 = TC_FOURPITHIRD * h3;
+        const tc_fdiv fd = tc_fdiv_setup(hf);
 
-        for (int kk = lane; kk < cnt; kk += 64) {
-            double r = rl.get(kk);
-            if (r > hsml) continue;            /* == (r2 > hsml^2) up to a zero-weight boundary, DESIGN.md */
-            float rf = (float)r;
-            double wk = tc_wc6(rf, hf, norm_h3);
-            double dwk = tc_dwc6(rf, hf, norm_h4);
-            wkNgb += TC_FOURPITHIRD * wk * h3;
-            rho += mpart * wk;
-            dRhodHsml += nmpart * (three_h * wk + r / hsml * dwk);
+        /* Per-entry arithmetic (src/sph.c:133-153, :426-440), trimmed for the VALU: the f32 quotient
+         * u = r/h is still correctly rounded (reciprocal + exact-residual correction); the f64
+         * polynomials use t^8 = ((t^2)^2)^2 and Horner/FMA forms and r/h becomes r*(1/h), which
+         * moves each f64 term by <= a few ulp (1e-16) -- the same size as the summation-order
+         * difference already present -- before wk / dwk are rounded to f32 as in the reference. */
+        auto term = [&](double r, double &a0, double &a1, double &a2) {
+            const float rf = (float)r;
+            const float u = tc_fdiv_apply(fd, rf);
+            const double ud = (double)u;
+            const double t = 1 - ud;
+            const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
+            const double poly = fma(ud, fma(ud, fma(ud, 32.0, 25.0), 8.0), 1.0);
+            const double wk = (double)(float)(norm_h3 * t8 * poly);
+            const double td = (double)(1 - u);
+            const double d2 = td * td, d4 = d2 * d2, d7 = d4 * d2 * td;
+            const float polyf = __builtin_fmaf(u, __builtin_fmaf(u, 16.0f, 7.0f), 1.0f);
+            const double dwk = (double)(float)(norm_h4 * d7 * ud * (double)polyf);
+            a0 = fma(fpt_h3, wk, a0);
+            a1 = fma(mpart, wk, a1);
+            a2 = fma(nmpart, fma(three_h, wk, r * inv_h * dwk), a2);
+        };
+        /* two independent entries per lane and trip: the f64 chains are latency-bound otherwise.
+         * `r > hsml` entries are skipped: == (r2 > hsml^2) up to a zero-weight boundary */
+        double wkB = 0, rhoB = 0, dRhoB = 0;
+        for (int kk = lane; kk < cnt; kk += 128) {
+            const int k2 = kk + 64;
+            double ra = rl.get(kk);
+            double rb = k2 < cnt ? rl.get(k2) : hsml;
+            /* a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0 */
+            ra = ra > hsml ? hsml : ra;
+            rb = rb > hsml ? hsml : rb;
+            term(ra, wkNgb, rho, dRhodHsml);
+            term(rb, wkB, rhoB, dRhoB);
         }
+        wkNgb += wkB; rho += rhoB; dRhodHsml += dRhoB;
         wkNgb = wsum(wkNgb);
         rho = wsum(rho);
         dRhodHsml = wsum(dRhodHsml);
@@ -339,7 +405,7 @@ __device__ __forceinline__ bool solve_hsml(const tc_rlist &rl, int cnt, double m
         } else {
             if (wkNgb > TC_DESNNGB) upper = hsml;
             if (wkNgb < TC_DESNNGB) lower = hsml;
-            hsml = pow(0.5 * ((lower * lower * lower) + (upper * upper * upper)), 1.0 / 3.0);
+            hsml = bisect_hsml(lower, upper);
         }
     }
 
@@ -357,7 +423,8 @@ __device__ __forceinline__ bool solve_hsml(const tc_rlist &rl, int cnt, double m
 }
 
 /* src/sph.c:21-71 for particle i */
-__device__ __forceinline__ void density_one(const tc_density_args &a, int i, const tc_rlist &rl, uint32_t *idx)
+__device__ __forceinline__ void density_one(const tc_density_args &a, int i, const tc_rlist &rl, uint32_t *idx,
+                                            const tc_stage &st)
 {
     const tc_dev_const &k = a.k;
     const int lane = lane_id();
@@ -375,22 +442,46 @@ __device__ __forceinline__ void density_one(const tc_density_args &a, int i, con
     bool ok = false;
 
     for (int guard = 0; guard < 4096; guard++) {
-        /* ---- ball query (src/tree.c:25-111), f32 predicate, list capped at NGBMAX */
+        /* ---- ball query (src/tree.c:25-111), f32 predicate, list capped at NGBMAX.
+         * Hits (about a third of the candidates) are first compacted into a 128-entry LDS ring of
+         * positions; the f64 pair distance is evaluated 64 hits at a time with every lane busy. */
         const float h2 = hsml * hsml;
-        int cnt = 0;
+        int cnt = 0, scnt = 0, head = 0;
         nq++;
+        auto convert = [&](int nvalid) {
+            wave_lds_fence();
+            int sl = (head + lane) & (TC_STAGE - 1);
+            float x = st.x[sl], y = st.y[sl], z = st.z[sl];
+            if (lane < nvalid) {
+                int slot = cnt + lane;
+                if (slot < TC_NGBMAX) rl.put(slot, tc_pair_r(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize));
+            }
+            cnt = U(cnt + nvalid);
+            head = U((head + 64) & (TC_STAGE - 1));
+            wave_lds_fence();
+        };
         ncand += stream_candidates(k, xi, yi, zi, hsml, idx, [&](int j, float4 p, bool act) -> bool {
             float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2 < h2);
             uint64_t m = __ballot(hit);
+            if (k.ablate == 2) { cnt += __popcll(m); return false; }
             if (hit) {
-                int slot = cnt + mask_rank(m);
-                if (slot < TC_NGBMAX) rl.put(slot, tc_pair_r(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize));
+                int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
+                st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z;
             }
-            cnt += __popcll(m);
-            return cnt >= TC_NGBMAX;
+            scnt = U(scnt + (int)__popcll(m));
+            if (scnt >= 64) { convert(64); scnt = U(scnt - 64); }
+            return cnt + scnt >= TC_NGBMAX;
         });
+        if (cnt + scnt < TC_NGBMAX && scnt > 0) convert(scnt);
+        else cnt += scnt;
+        cnt = U(cnt);
         wave_lds_fence();
+        if (k.ablate) {
+            if (k.ablate != 3 || cnt >= TC_DESNNGB) { ok = true; break; }
+            hsml = (float)((double)hsml * 1.23);
+            continue;
+        }
         if (cnt >= TC_NGBMAX) { hsml = (float)((double)hsml / 1.24); continue; }   /* src/sph.c:42-47 */
         if (cnt < TC_DESNNGB) { hsml = (float)((double)hsml * 1.23); continue; }   /* src/sph.c:49-54 */
 
@@ -414,7 +505,7 @@ __device__ __forceinline__ void density_one(const tc_density_args &a, int i, con
     }
 }
 
-#define TC_LDS_PER_WAVE_DENSITY (TC_RCAP * sizeof(double) + TC_IDXCAP * sizeof(uint32_t))
+#define TC_LDS_PER_WAVE_DENSITY (TC_RCAP * sizeof(double) + TC_IDXCAP * sizeof(uint32_t) + 3 * TC_STAGE * sizeof(float))
 #define TC_LDS_PER_WAVE_IDX (TC_IDXCAP * sizeof(uint32_t))
 
 __global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
@@ -427,7 +518,12 @@ __global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
     rl.lds = reinterpret_cast<double *>(mine);
     rl.spill = a.spill + (size_t)gw * (TC_NGBMAX - TC_RCAP);
     uint32_t *idx = reinterpret_cast<uint32_t *>(mine + TC_RCAP * sizeof(double));
-    for (int i = a.k.lo + gw; i < a.k.hi; i += nw) density_one(a, i, rl, idx);
+    tc_stage st;
+    st.x = reinterpret_cast<float *>(idx + TC_IDXCAP);
+    st.y = st.x + TC_STAGE;
+    st.z = st.y + TC_STAGE;
+    st.w = nullptr;
+    for (int i = a.k.lo + gw; i < a.k.hi; i += nw) density_one(a, i, rl, idx, st);
 }
 
 void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
@@ -449,6 +545,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     if (lo > hi) lo = hi;
     k->lo = (int)lo;
     k->hi = (int)hi;
+    k->ablate = c->ablate;
 }
 
 /* persistent grid: exactly the blocks that are co-resident (occupancy query), never more
@@ -512,15 +609,22 @@ __device__ __forceinline__ void wvt_pair(const float4 pi, const float4 pj, doubl
     float r2 = (dx * dx + dy * dy + dz * dz);
     float h = (float)(0.5 * (double)(pi.w + pj.w));
     if (r2 > h * h) return;
-    float r = (float)sqrt((double)r2);
-    float wk = (float)tc_wvt_wc6(r, h);
-    double base = step_hi * (double)wk;          /* (step * hsml_i) * wk */
-    d0 += base * (double)dx / (double)r;
-    d1 += base * (double)dy / (double)r;
-    d2 += base * (double)dz / (double)r;
+    /* (float)sqrt((double)r2) == sqrtf(r2): both are the correctly rounded f32 root */
+    float r = sqrtf(r2);
+    /* src/wvt_relax.c:275-281 with t^8 by squaring and a Horner/FMA polynomial (terms move by a few
+     * ulp of f64 before wk is rounded to f32, as in solve_hsml) */
+    const double u = (double)(r / h);
+    const double t = 1 - u;
+    const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
+    float wk = (float)(TC_WC6_NORM * t8 * fma(u, fma(u, fma(u, 32.0, 25.0), 8.0), 1.0));
+    /* step*hsml_i*wk*d/r for the three components with one reciprocal of r */
+    double base = step_hi * (double)wk * (1.0 / (double)r);
+    d0 = fma(base, (double)dx, d0);
+    d1 = fma(base, (double)dy, d1);
+    d2 = fma(base, (double)dz, d2);
 }
 
-__device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *idx)
+__device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *idx, const tc_stage &st)
 {
     const int lane = lane_id();
     const tc_dev_const &k = a.k;
@@ -531,14 +635,31 @@ __device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *i
     const double step_hi = a.step * (double)pi.w;
 
     double d0 = 0, d1 = 0, d2 = 0;
-    int cnt = 0;
+    int cnt = 0, scnt = 0, head = 0;
+    /* hits are compacted into the LDS ring first so that the pair arithmetic runs on full waves */
+    auto convert = [&](int nvalid) {
+        wave_lds_fence();
+        int sl = (head + lane) & (TC_STAGE - 1);
+        float4 p = make_float4(st.x[sl], st.y[sl], st.z[sl], st.w[sl]);
+        if (lane < nvalid) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
+        head = U((head + 64) & (TC_STAGE - 1));
+        wave_lds_fence();
+    };
     stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
         float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
         bool hit = act && (r2 < hq2);
         cnt += __popcll(__ballot(hit));
-        if (hit && j != i) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
+        bool use = hit && j != i;
+        uint64_t m = __ballot(use);
+        if (use) {
+            int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
+            st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = p.w;
+        }
+        scnt = U(scnt + (int)__popcll(m));
+        if (scnt >= 64) { convert(64); scnt = U(scnt - 64); }
         return false;
     });
+    if (scnt > 0) convert(scnt);
 
     if (cnt >= TC_NGBMAX) {
         /* The reference truncates the list to the first NGBMAX hits in ascending index
@@ -575,10 +696,16 @@ __device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *i
 __global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
 {
     __shared__ __align__(16) uint32_t lds_idx[WPB * TC_IDXCAP];
+    __shared__ __align__(16) float lds_stage[WPB * 4 * TC_STAGE];
     const int wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * WPB + wave, nw = gridDim.x * WPB;
     uint32_t *idx = lds_idx + (size_t)wave * TC_IDXCAP;
-    for (int i = a.k.lo + gw; i < a.k.hi; i += nw) wvt_one(a, i, idx);
+    tc_stage st;
+    st.x = lds_stage + (size_t)wave * 4 * TC_STAGE;
+    st.y = st.x + TC_STAGE;
+    st.z = st.y + TC_STAGE;
+    st.w = st.z + TC_STAGE;
+    for (int i = a.k.lo + gw; i < a.k.hi; i += nw) wvt_one(a, i, idx, st);
 }
 
 int tc_launch_wvt(tcgpu_ctx *c, double step)

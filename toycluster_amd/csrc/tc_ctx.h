@@ -16,7 +16,8 @@
 #define TC_RED_BLOCKS 1024       /* partial-sum slots of the streaming reductions */
 #define TC_RCAP 768              /* hit-list entries kept in LDS (f64 each); the rest spill */
 #define TC_IDXCAP 1024           /* candidate-index list per wave in LDS (u32 each) */
-#define TC_SMALLCELL 16          /* cells up to this size are expanded one lane per cell */
+#define TC_STAGE 128             /* ring of staged hit positions per wave (power of two, >= 128) */
+#define TC_SMALLCELL 64          /* cells up to this size are expanded one lane per cell */
 #define TC_MAX_PERSISTENT_BLOCKS 2048
 
 enum tc_phase {
@@ -36,6 +37,7 @@ struct tc_dev_const {
     const float4 *pos4;           /* x,y,z,(w = hsml_wvt) in Peano order */
     int n;                        /* all particles (neighbour candidates) */
     int lo, hi;                   /* [lo,hi): the particles this GPU solves for */
+    int ablate;                   /* profiling only: 1 producer only, 2 +predicate, 3 no solver (results invalid) */
 };
 
 TC_HD size_t tc_level_offset(int L) /* cells of levels 1..L-1 */
@@ -83,6 +85,7 @@ struct tcgpu_ctx {
     int index_valid;
     int level_shift;
     int lmax_override;
+    int ablate;
 
     /* scratch */
     float *guess;

@@ -156,6 +156,34 @@ TC_HD double tc_wvt_wc6(float r, float h)
     return TC_WC6_NORM * t * t * t * t * t * t * t * t * (1 + 8 * u + 25 * u * u + 32 * u * u * u);
 }
 
+/* Correctly rounded f32 quotient a/b for many a and one b without a per-element divide:
+ * q0 = a*y, rem = fma(-q0, b, a) (exact), q1 = fma(rem, y, q0) with y = RN(1/b) (Markstein).
+ * q1 == RN(a/b) unless b's significand is all ones or an intermediate leaves the normal range;
+ * those cases fall back to the divide. */
+typedef struct {
+    float b, y;
+    int exact_div;
+} tc_fdiv;
+
+TC_HD tc_fdiv tc_fdiv_setup(float b)
+{
+    tc_fdiv d;
+    d.b = b;
+    d.y = 1.0f / b;
+    union { float f; uint32_t u; } c;
+    c.f = b;
+    d.exact_div = ((c.u & 0x7fffffu) == 0x7fffffu) || !(b > 1e-30f && b < 1e30f);
+    return d;
+}
+
+TC_HD float tc_fdiv_apply(tc_fdiv d, float a)
+{
+    if (d.exact_div) return a / d.b;          /* wave-uniform: one b per wave */
+    float q0 = a * d.y;
+    float rem = __builtin_fmaf(-q0, d.b, a);
+    return __builtin_fmaf(rem, d.y, q0);
+}
+
 /* ------------------------------------------------------------------ density model */
 
 typedef struct {
