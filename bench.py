@@ -65,11 +65,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="testing: run the RCCL collectives through a 1-rank communicator")
     args = ap.parse_args()
+
+    # RCCL prints a version banner on stdout when a communicator is created; keep stdout clean for
+    # the one JSON line by pointing fd 1 at stderr until the result is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
-    from toycluster_amd import binding, model as M
+    from toycluster_amd import binding, model as M, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -81,15 +89,14 @@ def main():
     uid = None
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        box = [binding.comm_unique_id().tolist() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = np.array(box[0], dtype=np.uint8)
+        uid = shard.bootstrap_unique_id(dist, rank, binding.comm_unique_id)
 
     n_total = args.particles_per_gpu * world
     m = M.preset("merger", n_total)
     pos, ids = M.sample_gas(m, n_total, seed=14041981)       # same seed => same particles on every rank
 
-    g = binding.TcGpu(local_rank, rank=rank, nranks=world, unique_id=uid)
+    g = binding.TcGpu(local_rank, rank=rank, nranks=world, unique_id=uid,
+                      options={"force_comm": 1} if args.force_comm else None)
     g.set_model(m)
     g.upload(pos, ids)
     del pos, ids
@@ -157,7 +164,8 @@ def main():
             "cpu_baseline": cpu,
             "phase_ms_per_step": {k: 1e3 * v[0] / args.steps for k, v in phases.items() if v[1]},
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     g.close()
     if world > 1:
         dist.destroy_process_group()

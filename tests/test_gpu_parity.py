@@ -267,6 +267,27 @@ def test_curl_of_vector_potential(gpu, golden_case):
     assert np.abs(b - c["c_bfld"]).max() < 1e-5 * scale
 
 
+# ------------------------------------------------------------------ collectives (1-rank communicator)
+
+def test_rccl_code_path_single_rank(golden_case):
+    """The RCCL all-gather / all-reduce calls of the sharded path, exercised with a 1-rank
+    communicator on the one GPU of this box: results must equal the communicator-free path."""
+    c = golden_case
+    g = binding.TcGpu(0, options={"force_comm": 1})
+    try:
+        g.set_model(c["model"])
+        g.upload(c["pos"], c["ids"])
+        log = g.Regularise_sph_particles(max_iter=3)
+        p = g.particles()
+    finally:
+        g.close()
+    assert len(log) == len(c["r_log"])
+    for l, w in zip(log, c["r_log"]):
+        assert l["err_mean"] == pytest.approx(w[2], rel=1e-5)
+    assert np.array_equal(p["id"], c["r_ids"])
+    assert (np.abs(p["pos"] - c["r_pos"]).max(axis=1) / c["r_hsml"]).max() < TOL_POS
+
+
 # ------------------------------------------------------------------ error behaviour
 
 def test_out_of_box_coordinate_is_reported(gpu):

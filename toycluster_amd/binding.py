@@ -128,8 +128,8 @@ class TcGpu:
         self.n = 0
         for k, v in (options or {}).items():
             self.set_option(k, v)
-        if nranks > 1:
-            uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        if nranks > 1 or (options or {}).get("force_comm"):
+            uid = np.ascontiguousarray(unique_id if unique_id is not None else comm_unique_id(), dtype=np.uint8)
             self._ck(self._L.tcgpu_comm_init(self._h, int(rank), int(nranks), _p(uid)))
         self.rank, self.nranks = rank, nranks
 

@@ -15,6 +15,19 @@ static const char *PHASE_NAMES[PH_COUNT] = {"peano_keys", "radix_sort", "permute
                                             "density", "error_sums", "model_hsml", "wvt_sweep", "move",
                                             "curl", "comm"};
 
+struct rccl_api {
+    void *h;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+};
+static rccl_api g_rccl;
+
+
 /* ------------------------------------------------------------------ phase timing */
 
 void tc_phase_begin(tcgpu_ctx *c, int phase)
@@ -116,6 +129,7 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     free_particles(c);
     hipFree(c->d_halo); hipFree(c->red); hipHostFree(c->h_red); hipFree(c->flags); hipHostFree(c->h_flags);
     hipFree(c->orphans); hipFree(c->norph); hipFree(c->ngb_cnt); hipFree(c->spill);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -162,7 +176,7 @@ static int pick_lmax(int64_t n)
 static int ensure_capacity(tcgpu_ctx *c, int64_t n)
 {
     int64_t need = n;
-    if (c->nranks > 1) {                       /* all-gather needs nranks equal shards */
+    if (c->comm) {                       /* all-gather needs nranks equal shards */
         int64_t s = (n + c->nranks - 1) / c->nranks;
         need = s * c->nranks;
     }
@@ -290,24 +304,16 @@ static int check_flags(tcgpu_ctx *c)
 
 /* ------------------------------------------------------------------ RCCL (loaded on demand) */
 
-struct rccl_api {
-    void *h;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
-    ncclResult_t (*GroupStart)(void);
-    ncclResult_t (*GroupEnd)(void);
-    ncclResult_t (*CommDestroy)(ncclComm_t);
-};
-static rccl_api g_rccl;
-
 static int load_rccl(void)
 {
     if (g_rccl.h) return 0;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    /* Prefer an RCCL that is already mapped into the process (e.g. the copy PyTorch links): two RCCL
+     * builds side by side each keep their own device state.  Otherwise load ROCm's. */
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    void *h = nullptr;
+    for (int i = 0; i < 2 && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+    for (int i = 1; i >= 0 && !h; i--) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) return -1;
     g_rccl.GetUniqueId = (ncclResult_t(*)(ncclUniqueId *))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (ncclResult_t(*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(h, "ncclCommInitRank");
@@ -339,7 +345,7 @@ extern "C" int tcgpu_comm_init(tcgpu_ctx *c, int rank, int nranks, const uint8_t
 {
     if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return TCGPU_ERR_ARG;
     if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "tcgpu_comm_init must precede tcgpu_upload_particles");
-    if (nranks == 1) { c->rank = 0; c->nranks = 1; return TCGPU_OK; }
+    if (nranks == 1 && !c->force_comm) { c->rank = 0; c->nranks = 1; return TCGPU_OK; }
     if (load_rccl()) TC_FAIL(c, TCGPU_ERR_COMM, "cannot load librccl.so: %s", dlerror());
     TC_HIP(c, hipSetDevice(c->device));
     ncclUniqueId u;
@@ -460,7 +466,7 @@ static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess)
     if ((rc = tc_launch_cells(c))) return rc;
     if (need_guess && (rc = tc_launch_guess(c))) return rc;
     if ((rc = tc_launch_density(c))) return rc;
-    if (c->nranks > 1) {
+    if (c->comm) {
         tc_phase_begin(c, PH_COMM);
         g_rccl.GroupStart();
         int r1 = allgather_inplace(c, c->hsml[c->cur], sizeof(float));
@@ -548,7 +554,7 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
     if ((rc = tc_launch_wvt(c, step))) return rc;
     if (move) {
         if ((rc = tc_launch_move(c))) return rc;
-        if (c->nranks > 1) {
+        if (c->comm) {
             tc_phase_begin(c, PH_COMM);
             rc = allgather_inplace(c, c->pos4[c->cur], sizeof(float4));
             tc_phase_end(c);
@@ -581,7 +587,7 @@ static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, do
     if ((rc = find_sph_quantities_nocheck(c, need_guess))) return rc;
     if ((rc = tc_launch_error(c))) return rc;
     double *fin = c->red + 4 * TC_RED_BLOCKS;
-    if (c->nranks > 1) {
+    if (c->comm) {
         tc_phase_begin(c, PH_COMM);
         g_rccl.GroupStart();
         ncclResult_t r1 = g_rccl.AllReduce(fin, fin, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
@@ -661,7 +667,7 @@ extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *
     TC_HIP(c, hipStreamSynchronize(c->stream));
     int rc = tc_launch_curl(c);
     if (rc) return rc;
-    if (c->nranks > 1) {
+    if (c->comm) {
         tc_phase_begin(c, PH_COMM);
         rc = allgather_inplace(c, c->bfld, 3 * sizeof(float));
         tc_phase_end(c);
@@ -682,6 +688,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "timing")) c->timing = value != 0;
     else if (!strcmp(name, "level_shift")) c->level_shift = (int)value;
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
+    else if (!strcmp(name, "force_comm")) c->force_comm = value != 0;   /* tests: 1-rank RCCL communicator */
     else if (!strcmp(name, "lmax")) {
         if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "lmax must be set before tcgpu_upload_particles");
         c->lmax_override = (int)value;

@@ -103,6 +103,7 @@ struct tcgpu_ctx {
     /* sharding */
     int rank, nranks;
     void *comm;                   /* ncclComm_t */
+    int force_comm;
     int64_t shard_len;
 
     /* phase timing */
