@@ -1,0 +1,92 @@
+/*
+ * tc_host.h -- C host side of the MI355X Toycluster path: the reference's run-time interface
+ * (parameter file in, Gadget-2 "format 2" snapshot out) around libtcgpu.
+ *
+ *   parameter file : reference src/io.c:298-507 (Read_param_file) -- `tag value` lines, `%` comments,
+ *                    unknown tags ignored, every known tag mandatory
+ *   snapshot       : reference src/io.c:13-287 + src/io.h:1-41 -- HEAD, POS, VEL, ID, U, RHO, HSML,
+ *                    BFLD, RHOM blocks, each preceded by an 8-byte label record, all wrapped in
+ *                    4-byte Fortran record markers
+ *   state file     : this repo's exchange format for what the hot path consumes (model scalars +
+ *                    gas positions + ids; SURVEY.md Appendix A "hot-path state file")
+ */
+#ifndef TC_HOST_H
+#define TC_HOST_H
+
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tcgpu.h"
+
+#define TC_CHARBUF 512        /* reference CHARBUFSIZE, src/globals.h:37 */
+
+/* ---- parameter file (the tags of the default build: Makefile:3-25 without GIVEPARAMS etc.) ---- */
+typedef struct {
+    char   output_file[TC_CHARBUF];   /* Output_file */
+    long long ntotal;                 /* Ntotal   (read with atoi, src/io.c:476-478) */
+    double mtot200;                   /* Mtotal -> Param.Mtot200 (src/io.c:319-321) */
+    double redshift;                  /* Redshift */
+    double mass_ratio;                /* Mass_Ratio */
+    double impact_param;              /* ImpactParam */
+    double zero_e_orbit_frac;         /* ZeroEOrbitFrac */
+    int    cuspy;                     /* Cuspy */
+    double bfld_norm;                 /* Bfld_Norm */
+    double bfld_eta;                  /* Bfld_Eta */
+    double baryon_fraction;           /* bf */
+    double unit_length, unit_mass, unit_vel;   /* UnitLength_in_cm, UnitMass_in_g, UnitVelocity_in_cm_per_s */
+} tc_parfile;
+
+/* 0 on success; 1 = file not found, 2 = a tag is missing (both fatal in the reference: exit(1)).
+ * err receives the reference's message. */
+int tc_read_param_file(const char *filename, tc_parfile *out, char *err, size_t errlen);
+
+/* ---- Gadget-2 format-2 snapshot ---- */
+typedef struct {                      /* src/io.h:1-19, 256 bytes */
+    int32_t  npart[6];
+    double   mass[6];
+    double   time;
+    double   redshift;
+    int32_t  flag_sfr;
+    int32_t  flag_feedback;
+    uint32_t npartTotal[6];
+    int32_t  flag_cooling;
+    int32_t  num_files;
+    double   BoxSize;
+    double   Omega0;
+    double   OmegaLambda;
+    double   HubbleParam;
+    int32_t  flag_stellarage;
+    int32_t  flag_metals;
+    uint32_t npartTotalHighWord[6];
+    char     fill[64];
+} tc_gadget_header;
+
+typedef struct {
+    long long npart[6];               /* Param.Npart */
+    double mpart[6];                  /* Param.Mpart */
+    double boxsize;
+    double hubble_param;              /* Cosmo.h_100 (0.7, src/cosmo.c:11) */
+    /* all particles, gas first: */
+    const float *pos;                 /* 3*ntot */
+    const float *vel;                 /* 3*ntot */
+    const int32_t *id;                /* ntot */
+    /* gas only (npart[0]): */
+    const float *u, *rho, *hsml, *bfld /* 3*ngas */, *rho_model;
+} tc_snapshot;
+
+/* 0 on success, 5/6 on I/O error (the reference's exit codes, src/io.c:256,280) */
+int tc_write_snapshot(const char *filename, const tc_snapshot *s);
+
+/* ---- state file ---- */
+typedef struct {
+    tcgpu_params par;
+    tcgpu_halo *halos;                /* par.nhalos entries */
+    int64_t ngas;
+    float *pos;                       /* 3*ngas, in [0, boxsize] */
+    int32_t *id;                      /* ngas */
+} tc_state;
+
+int  tc_read_state(const char *filename, tc_state *st, char *err, size_t errlen);
+int  tc_write_state(const char *filename, const tc_state *st);
+void tc_free_state(tc_state *st);
+
+#endif

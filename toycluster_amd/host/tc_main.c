@@ -1,0 +1,142 @@
+/*
+ * toycluster_hip -- C host program for the MI355X SPH/WVT path.
+ *
+ *   usage: ./toycluster_hip <parameterfile> <statefile> [device]
+ *
+ * It is the gas branch of the reference's main() (src/main.c:50-69) with the hot path running on
+ * the GPU through libtcgpu's C ABI:
+ *     Regularise_sph_particles();   src/main.c:52  -> tcgpu_regularise_sph_particles()
+ *     Find_sph_quantities();        src/main.c:54  -> tcgpu_find_sph_quantities()
+ *     Make_magnetic_field();        src/main.c:56  -> A from the model (src/magnetic_field.c:33-69),
+ *                                                     tcgpu_bfld_from_rotA_sph(), normalisation
+ *                                                     (src/magnetic_field.c:71-131, race-free max)
+ *     Write_output();               src/main.c:69  -> tc_write_snapshot()
+ * The steps before the hot path (halo set-up, sampling: SURVEY.md 8f-2) are not re-implemented yet;
+ * their result -- model scalars, gas positions, ids -- comes from the state file.  Temperatures and
+ * velocities (out of scope) are written as zeros.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "tc_host.h"
+
+#define BMAX 18e-6   /* src/magnetic_field.c:4 */
+
+static void die(int code, const char *what, const char *msg)
+{
+    fprintf(stderr, "\nERROR : %s: %s\n\n", what, msg);
+    exit(code);
+}
+
+/* src/setup.c:598-615 */
+static double gas_density_profile(double r, const tcgpu_halo *h)
+{
+    double a = r / h->rcore, b = r / h->rcut;
+    return h->rho0 * pow(1 + a * a, -3.0 / 2.0 * h->beta) / (1 + (b * b * b) * b);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) {
+        fprintf(stderr, "usage : ./toycluster_hip $parameterfile $statefile [device]\n");
+        return EXIT_FAILURE;
+    }
+    char err[1024];
+    tc_parfile par;
+    if (tc_read_param_file(argv[1], &par, err, sizeof(err))) { fprintf(stderr, "%s\n", err); return 1; }   /* exit(1) */
+    printf("\nReading Parameter file : %s \n\n", argv[1]);
+
+    tc_state st;
+    if (tc_read_state(argv[2], &st, err, sizeof(err))) die(EXIT_FAILURE, "state file", err);
+    st.par.bfld_eta = par.bfld_eta;
+    const size_t n = (size_t)st.ngas;
+
+    tcgpu_ctx *ctx = NULL;
+    int rc = tcgpu_create(&ctx, argc > 3 ? atoi(argv[3]) : 0);
+    if (rc) die(EXIT_FAILURE, "tcgpu_create", "no usable gfx950 device");
+#define CK(call) do { if ((rc = (call))) die(EXIT_FAILURE, #call, tcgpu_last_error(ctx)); } while (0)
+    CK(tcgpu_set_model(ctx, &st.par, st.halos));
+    CK(tcgpu_upload_particles(ctx, st.ngas, st.pos, st.id, NULL));
+
+    /* ---- Regularise_sph_particles(): banner and log lines of src/wvt_relax.c:31-34,91-92,222 */
+    printf("Starting iterative SPH regularisation \n"
+           "   max %d iterations, tree update every %d iterations\n"
+           "   stop at  errmax < %g%%   \n\n", TCGPU_NUMITER, 1, 0.01 * 100);
+    fflush(stdout);
+    tcgpu_iterlog log[TCGPU_MAXLOG];
+    int32_t nlog = 0;
+    CK(tcgpu_regularise_sph_particles(ctx, -1, log, &nlog));
+    for (int i = 0; i < nlog && i < TCGPU_MAXLOG; i++)
+        printf("   #%02d: Err max=%3g mean=%03g diff=%03g step=%g\n", log[i].it, log[i].err_max, log[i].err_mean,
+               log[i].err_diff, log[i].step);
+    printf("\ndone\n\n");
+    fflush(stdout);
+
+    /* ---- Find_sph_quantities() */
+    CK(tcgpu_find_sph_quantities(ctx));
+
+    float *pos = malloc(3 * n * sizeof(float)), *hsml = malloc(n * sizeof(float)), *rho = malloc(n * sizeof(float));
+    float *rhom = malloc(n * sizeof(float)), *apot = malloc(3 * n * sizeof(float)), *bfld = malloc(3 * n * sizeof(float));
+    float *zeros = calloc(3 * n, sizeof(float));
+    int32_t *id = malloc(n * sizeof(int32_t));
+    if (!pos || !hsml || !rho || !rhom || !apot || !bfld || !zeros || !id) die(EXIT_FAILURE, "malloc", "out of memory");
+    CK(tcgpu_download_particles(ctx, pos, id, hsml, rho, NULL, rhom));
+
+    /* ---- Make_magnetic_field() */
+    printf("Magnetic field: \n   B0              = %g G\n   eta             = %g \n\n", par.bfld_norm, par.bfld_eta);
+    const float boxhalf = 0.5 * st.par.boxsize;
+    for (size_t i = 0; i < n; i++) {                                   /* src/magnetic_field.c:38-66 */
+        double a_max = 0;
+        for (int k = 0; k < st.par.nhalos; k++) {
+            const tcgpu_halo *h = &st.halos[k];
+            if (h->mass_gas == 0) continue;
+            float dx = pos[3 * i] - h->d_com[0] - boxhalf, dy = pos[3 * i + 1] - h->d_com[1] - boxhalf,
+                  dz = pos[3 * i + 2] - h->d_com[2] - boxhalf;
+            double r2 = dx * dx + dy * dy + dz * dz;
+            double a = pow(gas_density_profile(sqrt(r2), h) / h->rho0, par.bfld_eta);
+            if (a > a_max) a_max = a;
+        }
+        apot[3 * i] = apot[3 * i + 1] = apot[3 * i + 2] = (float)a_max;
+    }
+    printf("Constructing B from rot(A)"); fflush(stdout);
+    CK(tcgpu_bfld_from_rotA_sph(ctx, apot, bfld));
+    printf(" done \n\n");
+    double max_b2 = 0;                                                  /* src/magnetic_field.c:75-85, without the race */
+    for (size_t i = 0; i < n; i++) {
+        double b2 = (double)bfld[3 * i] * bfld[3 * i] + (double)bfld[3 * i + 1] * bfld[3 * i + 1]
+                    + (double)bfld[3 * i + 2] * bfld[3 * i + 2];
+        max_b2 = fmax(max_b2, b2);
+    }
+    double norm = par.bfld_norm / sqrt(max_b2) / sqrt(3);
+    printf("Bfld Norm = %g \n", norm);
+    int cnt = 0;
+    for (size_t i = 0; i < n; i++) {                                    /* src/magnetic_field.c:96-126 */
+        for (int c = 0; c < 3; c++) bfld[3 * i + c] *= norm;
+        double B2 = (double)bfld[3 * i] * bfld[3 * i] + (double)bfld[3 * i + 1] * bfld[3 * i + 1]
+                    + (double)bfld[3 * i + 2] * bfld[3 * i + 2];
+        if (B2 > BMAX * BMAX) {
+            double B = sqrt(B2);
+            for (int c = 0; c < 3; c++) bfld[3 * i + c] *= BMAX / B;
+            cnt++;
+        }
+    }
+    printf("Bfld of %d particles limited to %g G\n", cnt, BMAX);
+
+    /* ---- Write_output() */
+    tc_snapshot s;
+    memset(&s, 0, sizeof(s));
+    s.npart[0] = st.ngas;
+    s.mpart[0] = st.par.mpart_gas;
+    s.boxsize = st.par.boxsize;
+    s.hubble_param = 0.7;                                               /* src/cosmo.c:11 */
+    s.pos = pos; s.vel = zeros; s.id = id; s.u = zeros; s.rho = rho; s.hsml = hsml; s.bfld = bfld; s.rho_model = rhom;
+    printf("Output : \n   File Name = %s\n", par.output_file);
+    rc = tc_write_snapshot(par.output_file, &s);
+    if (rc) { fprintf(stderr, "I/O error (fwrite) "); return rc; }
+    printf("done\n");
+
+    tcgpu_destroy(ctx);
+    tc_free_state(&st);
+    free(pos); free(hsml); free(rho); free(rhom); free(apot); free(bfld); free(zeros); free(id);
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,114 @@
+"""Python access to the C host routines (toycluster_amd/host -> lib/libtchost.so) and readers for
+the files they produce.  Used by the tests and by tools that prepare inputs for `toycluster_hip`."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from .binding import TcHalo, TcParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOSTLIB = os.path.join(_HERE, "lib", "libtchost.so")
+EXE = os.path.join(_HERE, "host", "toycluster_hip")
+SHIMLIB = os.path.join(_HERE, "lib", "libtcshim.so")
+
+
+class ParFile(C.Structure):
+    _fields_ = [("output_file", C.c_char * 512), ("ntotal", C.c_longlong), ("mtot200", C.c_double),
+                ("redshift", C.c_double), ("mass_ratio", C.c_double), ("impact_param", C.c_double),
+                ("zero_e_orbit_frac", C.c_double), ("cuspy", C.c_int), ("bfld_norm", C.c_double),
+                ("bfld_eta", C.c_double), ("baryon_fraction", C.c_double), ("unit_length", C.c_double),
+                ("unit_mass", C.c_double), ("unit_vel", C.c_double)]
+
+
+class Snapshot(C.Structure):
+    _fields_ = [("npart", C.c_longlong * 6), ("mpart", C.c_double * 6), ("boxsize", C.c_double),
+                ("hubble_param", C.c_double), ("pos", C.c_void_p), ("vel", C.c_void_p), ("id", C.c_void_p),
+                ("u", C.c_void_p), ("rho", C.c_void_p), ("hsml", C.c_void_p), ("bfld", C.c_void_p),
+                ("rho_model", C.c_void_p)]
+
+
+def _lib():
+    if not os.path.exists(HOSTLIB):
+        raise RuntimeError("%s missing: run __graft_entry__.build()" % HOSTLIB)
+    L = C.CDLL(HOSTLIB)
+    L.tc_read_param_file.argtypes = [C.c_char_p, C.POINTER(ParFile), C.c_char_p, C.c_size_t]
+    L.tc_write_snapshot.argtypes = [C.c_char_p, C.POINTER(Snapshot)]
+    return L
+
+
+def read_param_file(path):
+    """Returns (rc, dict-or-None, message) with the reference's semantics (io.c:298-507)."""
+    p = ParFile()
+    err = C.create_string_buffer(1024)
+    rc = _lib().tc_read_param_file(path.encode(), C.byref(p), err, 1024)
+    if rc:
+        return rc, None, err.value.decode()
+    d = {k: getattr(p, k) for k, _ in ParFile._fields_}
+    d["output_file"] = d["output_file"].decode()
+    return 0, d, ""
+
+
+def write_snapshot(path, npart, mpart, boxsize, pos, vel, ids, u, rho, hsml, bfld, rho_model, hubble=0.7):
+    keep = [np.ascontiguousarray(a, dtype=t) for a, t in ((pos, np.float32), (vel, np.float32), (ids, np.int32),
+            (u, np.float32), (rho, np.float32), (hsml, np.float32), (bfld, np.float32), (rho_model, np.float32))]
+    s = Snapshot()
+    for i in range(6):
+        s.npart[i] = int(npart[i])
+        s.mpart[i] = float(mpart[i])
+    s.boxsize, s.hubble_param = boxsize, hubble
+    (s.pos, s.vel, s.id, s.u, s.rho, s.hsml, s.bfld, s.rho_model) = [a.ctypes.data for a in keep]
+    return _lib().tc_write_snapshot(path.encode(), C.byref(s))
+
+
+def read_snapshot(path):
+    """Minimal Gadget-2 format-2 reader: {label: raw bytes}, plus the parsed header."""
+    blocks = {}
+    order = []
+    with open(path, "rb") as f:
+        data = f.read()
+    off = 0
+    while off < len(data):
+        m0, = struct.unpack_from("<i", data, off)
+        assert m0 == 8, "label record marker"
+        label = data[off + 4:off + 8].decode()
+        nxt, m1 = struct.unpack_from("<ii", data, off + 8)
+        assert m1 == 8
+        off += 16
+        n0, = struct.unpack_from("<i", data, off)
+        assert n0 + 8 == nxt, "next-block length = payload + 2 markers"
+        payload = data[off + 4:off + 4 + n0]
+        n1, = struct.unpack_from("<i", data, off + 4 + n0)
+        assert n1 == n0
+        off += 8 + n0
+        blocks[label] = payload
+        order.append(label)
+    h = blocks["HEAD"]
+    assert len(h) == 256
+    header = dict(npart=struct.unpack_from("<6i", h, 0), mass=struct.unpack_from("<6d", h, 24),
+                  time=struct.unpack_from("<d", h, 72)[0], redshift=struct.unpack_from("<d", h, 80)[0],
+                  npartTotal=struct.unpack_from("<6I", h, 96), num_files=struct.unpack_from("<i", h, 124)[0],
+                  BoxSize=struct.unpack_from("<d", h, 128)[0], Omega0=struct.unpack_from("<d", h, 136)[0],
+                  OmegaLambda=struct.unpack_from("<d", h, 144)[0], HubbleParam=struct.unpack_from("<d", h, 152)[0])
+    return header, blocks, order
+
+
+def write_state(path, model, pos, ids):
+    """The hot-path state file consumed by `toycluster_hip` (host/tc_state.c)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    par = TcParams(model.boxsize, model.mpart_gas, model.mtotal, getattr(model, "bfld_eta", 0.5), len(model.halos), 0)
+    with open(path, "wb") as f:
+        f.write(b"TCSTATE1")
+        f.write(struct.pack("<q", len(ids)))
+        f.write(bytes(par))
+        for h in model.halos:
+            th = TcHalo()
+            th.mass_gas = h.mass_gas
+            for c in range(3):
+                th.d_com[c] = h.d_com[c]
+            th.rho0, th.beta, th.rcore, th.rcut, th.have_cuspy = h.rho0, h.beta, h.rcore, h.rcut, int(h.have_cuspy)
+            f.write(bytes(th))
+        f.write(pos.tobytes())
+        f.write(ids.tobytes())
