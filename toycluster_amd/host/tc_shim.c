@@ -81,7 +81,7 @@ static int cmp_idpair(const void *a, const void *b)
 }
 
 /* device -> P/SphP: whole structs are moved to the new (Peano) order, joined on the particle ID */
-static void pull_particles(int with_keys)
+static void pull_particles(int with_keys, int with_rho_model)
 {
     const size_t n = (size_t)Param.Npart[0];
     float *pos = malloc(3 * n * sizeof(float)), *hsml = malloc(n * sizeof(float)), *rho = malloc(n * sizeof(float));
@@ -109,7 +109,8 @@ static void pull_particles(int with_keys)
         Pn[i].Pos[0] = pos[3 * i]; Pn[i].Pos[1] = pos[3 * i + 1]; Pn[i].Pos[2] = pos[3 * i + 2];
         if (khi) Pn[i].Key = ((peanoKey)khi[i] << 64) | klo[i];
         Pn[i].Tree_Parent = 0;                    /* no tree is built; only the replaced files read it */
-        Sn[i].Hsml = hsml[i]; Sn[i].Rho = rho[i]; Sn[i].VarHsmlFac = vhf[i]; Sn[i].Rho_Model = rhom[i];
+        Sn[i].Hsml = hsml[i]; Sn[i].Rho = rho[i]; Sn[i].VarHsmlFac = vhf[i];
+        if (with_rho_model) Sn[i].Rho_Model = rhom[i];   /* only the WVT loop writes it (wvt_relax.c:113) */
     }
     memcpy(P, Pn, n * sizeof(*Pn));
     memcpy(SphP, Sn, n * sizeof(*Sn));
@@ -121,7 +122,7 @@ void Sort_Particles_By_Peano_Key(void)
 {
     ensure_ctx(); push_model(); push_particles();
     CK(tcgpu_sort_particles_by_peano_key(g_ctx));
-    pull_particles(1);
+    pull_particles(1, 0);
 }
 
 /* ---- src/proto.h:17 ---- */
@@ -129,7 +130,7 @@ void Find_sph_quantities(void)
 {
     ensure_ctx(); push_model(); push_particles();
     CK(tcgpu_find_sph_quantities(g_ctx));
-    pull_particles(1);
+    pull_particles(1, 0);
 }
 
 /* ---- src/proto.h:25 ---- */
@@ -148,7 +149,7 @@ void Regularise_sph_particles(void)
                log[i].err_diff, log[i].step);
     printf("\ndone\n\n");
     fflush(stdout);
-    pull_particles(0);
+    pull_particles(0, 1);
 }
 
 /* ---- src/proto.h:23, src/sph.h:2 : uses the neighbour index of the preceding Find_sph_quantities() ---- */
