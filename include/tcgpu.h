@@ -141,6 +141,12 @@ int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *ctx, const float *apot, float *bfld);
 int tcgpu_comm_unique_id(uint8_t id[128]);
 int tcgpu_comm_init(tcgpu_ctx *ctx, int rank, int nranks, const uint8_t id[128]);
 
+/* Testing only: tie `nranks` contexts of ONE process (one host thread each, any devices -- also all on
+ * the same GPU) into a loopback communicator whose collectives are barriers + device-to-device
+ * copies with the shard arithmetic of the RCCL path.  Lets a single-GPU box verify the sharded
+ * control flow.  Must precede tcgpu_upload_particles on every context. */
+int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
+
 /* ---- tuning / introspection ------------------------------------------------------- */
 int tcgpu_set_option(tcgpu_ctx *ctx, const char *name, double value);
 /* Seconds spent on the device in each phase since the last reset (HIP events on the

@@ -288,6 +288,55 @@ def test_rccl_code_path_single_rank(golden_case):
     assert (np.abs(p["pos"] - c["r_pos"]).max(axis=1) / c["r_hsml"]).max() < TOL_POS
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_path_with_loopback_ranks(nranks):
+    """The multi-GPU control flow (Peano-range shards, in-place all-gathers of hsml/rho/vhf and
+    positions, all-reduced error sums) run by `nranks` host threads on this one GPU through the
+    loopback communicator: every rank must end with the single-rank result."""
+    import threading
+    n = 20011                                       # not a multiple of nranks: padded tail shard
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=23)
+    g1 = binding.TcGpu(0)
+    g1.set_model(m)
+    g1.upload(pos, ids)
+    log1 = g1.Regularise_sph_particles(max_iter=4)
+    g1.Find_sph_quantities()
+    p1 = g1.particles()
+    g1.close()
+
+    ctxs = [binding.TcGpu(0) for _ in range(nranks)]
+    binding.loopback_group(ctxs)
+    out = [None] * nranks
+
+    def run(r):
+        try:
+            g = ctxs[r]
+            g.set_model(m)
+            g.upload(pos, ids)
+            log = g.Regularise_sph_particles(max_iter=4)
+            g.Find_sph_quantities()
+            out[r] = (log, g.particles())
+        except Exception as e:                      # pragma: no cover
+            out[r] = e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    for c in ctxs:
+        c.close()
+    for r in range(nranks):
+        assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
+        log, p = out[r]
+        assert len(log) == len(log1)
+        for a, b in zip(log, log1):
+            assert a["step"] == b["step"] and a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-12)
+            assert a["err_max"] == b["err_max"]
+        for k in ("id", "pos", "hsml", "rho", "varhsmlfac"):
+            assert np.array_equal(p[k], p1[k]), (r, k)
+
+
 # ------------------------------------------------------------------ error behaviour
 
 def test_out_of_box_coordinate_is_reported(gpu):

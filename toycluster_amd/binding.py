@@ -50,7 +50,8 @@ EXPORTS = [
     "tcgpu_sort_particles_by_peano_key", "tcgpu_download_keys", "tcgpu_peano_keys",
     "tcgpu_find_sph_quantities", "tcgpu_last_density_stats", "tcgpu_global_density_model", "tcgpu_find_ngb",
     "tcgpu_build_neighbour_index", "tcgpu_guess_hsml", "tcgpu_wvt_step", "tcgpu_density_error", "tcgpu_regularise_sph_particles",
-    "tcgpu_bfld_from_rotA_sph", "tcgpu_comm_unique_id", "tcgpu_comm_init", "tcgpu_set_option",
+    "tcgpu_bfld_from_rotA_sph", "tcgpu_comm_unique_id", "tcgpu_comm_init", "tcgpu_comm_init_loopback",
+    "tcgpu_set_option",
     "tcgpu_phase_times", "tcgpu_stream",
 ]
 
@@ -91,6 +92,7 @@ def lib():
         L.tcgpu_bfld_from_rotA_sph.argtypes = [vp, vp, vp]
         L.tcgpu_comm_unique_id.argtypes = [vp]
         L.tcgpu_comm_init.argtypes = [vp, i32, i32, vp]
+        L.tcgpu_comm_init_loopback.argtypes = [C.POINTER(vp), i32]
         L.tcgpu_set_option.argtypes = [vp, C.c_char_p, dbl]
         L.tcgpu_phase_times.argtypes = [vp, vp, vp, vp, C.POINTER(i32), i32]
         L.tcgpu_stream.argtypes = [vp]
@@ -113,6 +115,17 @@ def comm_unique_id():
     if rc:
         raise TcGpuError("tcgpu_comm_unique_id failed (%s)" % _ERR.get(rc, rc))
     return buf
+
+
+def loopback_group(contexts):
+    """Testing: make `contexts` (one per host thread, possibly all on one GPU) ranks of an in-process
+    loopback communicator (tcgpu_comm_init_loopback)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = lib().tcgpu_comm_init_loopback(arr, len(contexts))
+    if rc:
+        raise TcGpuError("tcgpu_comm_init_loopback failed (%s)" % _ERR.get(rc, rc))
+    for r, c in enumerate(contexts):
+        c.rank, c.nranks = r, len(contexts)
 
 
 class TcGpu:

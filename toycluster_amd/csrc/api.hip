@@ -4,6 +4,7 @@
  * src/sph.c:13-17).  All device work is enqueued on the context's own HIP stream.
  */
 #include <dlfcn.h>
+#include <pthread.h>
 #include <math.h>
 #include <float.h>
 #include <stdlib.h>
@@ -26,6 +27,17 @@ struct rccl_api {
     ncclResult_t (*CommDestroy)(ncclComm_t);
 };
 static rccl_api g_rccl;
+
+/* Test-only communicator: R contexts driven by R host threads of ONE process (any devices, also all
+ * on the same GPU).  Collectives = pthread barrier + device-to-device copies, with exactly the
+ * offsets and shard arithmetic of the RCCL path, so the sharded control flow can be verified on a
+ * single-GPU box.  Never used by the product path (tcgpu_comm_init installs RCCL). */
+struct tc_loop_comm {
+    int nranks;
+    pthread_barrier_t bar;
+    void *bufs[16];
+    double red[16][4];
+};
 
 
 /* ------------------------------------------------------------------ phase timing */
@@ -176,7 +188,7 @@ static int pick_lmax(int64_t n)
 static int ensure_capacity(tcgpu_ctx *c, int64_t n)
 {
     int64_t need = n;
-    if (c->comm) {                       /* all-gather needs nranks equal shards */
+    if (c->comm || c->loop) {                       /* all-gather needs nranks equal shards */
         int64_t s = (n + c->nranks - 1) / c->nranks;
         need = s * c->nranks;
     }
@@ -257,6 +269,12 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
     TC_HIP(c, hipStreamSynchronize(c->stream));
     c->keys_valid = 0;
     c->index_valid = 0;
+    c->need_guess = 1;
+    if (hsml) {                                   /* warm start: the guess is only read where hsml == 0 */
+        c->need_guess = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (hsml[i] == 0) { c->need_guess = 1; break; }
+    }
     return TCGPU_OK;
 }
 
@@ -362,10 +380,66 @@ extern "C" int tcgpu_comm_init(tcgpu_ctx *c, int rank, int nranks, const uint8_t
 static int allgather_inplace(tcgpu_ctx *c, void *base, size_t esize)
 {
     size_t bytes = (size_t)c->shard_len * esize;
+    if (c->loop) {
+        tc_loop_comm *L = c->loop;
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        L->bufs[c->rank] = base;
+        pthread_barrier_wait(&L->bar);
+        for (int p = 0; p < L->nranks; p++)
+            if (p != c->rank)
+                TC_HIP(c, hipMemcpyAsync((char *)L->bufs[p] + (size_t)c->rank * bytes,
+                                         (const char *)base + (size_t)c->rank * bytes, bytes,
+                                         hipMemcpyDeviceToDevice, c->stream));
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        pthread_barrier_wait(&L->bar);
+        return 0;
+    }
     ncclResult_t r = g_rccl.AllGather((const char *)base + (size_t)c->rank * bytes, base, bytes, ncclInt8,
                                       (ncclComm_t)c->comm, c->stream);
     if (r != ncclSuccess) TC_FAIL(c, TCGPU_ERR_COMM, "ncclAllGather failed (%d)", (int)r);
     return 0;
+}
+
+/* all-reduce of the error sums: fin[0], fin[1] summed, fin[3] maximised over the ranks */
+static int allreduce_error_sums(tcgpu_ctx *c, double *fin)
+{
+    if (c->loop) {
+        tc_loop_comm *L = c->loop;
+        double h[4];
+        TC_HIP(c, hipMemcpyAsync(h, fin, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(L->red[c->rank], h, sizeof(h));
+        pthread_barrier_wait(&L->bar);
+        double o[4] = {0, 0, 0, 0};
+        for (int p = 0; p < L->nranks; p++) { o[0] += L->red[p][0]; o[1] += L->red[p][1]; o[3] = fmax(o[3], L->red[p][3]); }
+        pthread_barrier_wait(&L->bar);
+        TC_HIP(c, hipMemcpyAsync(fin, o, sizeof(o), hipMemcpyHostToDevice, c->stream));
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    g_rccl.GroupStart();
+    ncclResult_t r1 = g_rccl.AllReduce(fin, fin, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
+    ncclResult_t r2 = g_rccl.AllReduce(fin + 3, fin + 3, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream);
+    g_rccl.GroupEnd();
+    if (r1 != ncclSuccess || r2 != ncclSuccess) TC_FAIL(c, TCGPU_ERR_COMM, "ncclAllReduce failed");
+    return 0;
+}
+
+/* testing: tie `nranks` contexts of this process into a loopback communicator (one thread each) */
+extern "C" int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks)
+{
+    if (!ctxs || nranks < 1 || nranks > 16) return TCGPU_ERR_ARG;
+    tc_loop_comm *L = (tc_loop_comm *)calloc(1, sizeof(*L));
+    if (!L) return TCGPU_ERR_NOMEM;
+    L->nranks = nranks;
+    pthread_barrier_init(&L->bar, nullptr, (unsigned)nranks);
+    for (int r = 0; r < nranks; r++) {
+        if (!ctxs[r] || ctxs[r]->n > 0) { free(L); return TCGPU_ERR_ARG; }
+        ctxs[r]->loop = L;              /* shared; intentionally leaked with the last context (test only) */
+        ctxs[r]->rank = r;
+        ctxs[r]->nranks = nranks;
+    }
+    return TCGPU_OK;
 }
 
 /* ------------------------------------------------------------------ sort / index */
@@ -466,13 +540,13 @@ static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess)
     if ((rc = tc_launch_cells(c))) return rc;
     if (need_guess && (rc = tc_launch_guess(c))) return rc;
     if ((rc = tc_launch_density(c))) return rc;
-    if (c->comm) {
+    if (c->comm || c->loop) {
         tc_phase_begin(c, PH_COMM);
-        g_rccl.GroupStart();
+        if (c->comm) g_rccl.GroupStart();
         int r1 = allgather_inplace(c, c->hsml[c->cur], sizeof(float));
         int r2 = allgather_inplace(c, c->rho[c->cur], sizeof(float));
         int r3 = allgather_inplace(c, c->vhf[c->cur], sizeof(float));
-        g_rccl.GroupEnd();
+        if (c->comm) g_rccl.GroupEnd();
         tc_phase_end(c);
         if (r1 || r2 || r3) return TCGPU_ERR_COMM;
     }
@@ -483,10 +557,11 @@ extern "C" int tcgpu_find_sph_quantities(tcgpu_ctx *c)
 {
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
-    int rc = find_sph_quantities_nocheck(c, 1);   /* guess is cheap; only read where hsml == 0 */
+    int rc = find_sph_quantities_nocheck(c, c->need_guess);
     if (rc) return rc;
     rc = check_flags(c);
     if (rc) return rc;
+    c->need_guess = 0;                            /* every hsml is > 0 after a successful pass */
     if (c->want_stats) return density_stats(c);
     return TCGPU_OK;
 }
@@ -554,7 +629,7 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
     if ((rc = tc_launch_wvt(c, step))) return rc;
     if (move) {
         if ((rc = tc_launch_move(c))) return rc;
-        if (c->comm) {
+        if (c->comm || c->loop) {
             tc_phase_begin(c, PH_COMM);
             rc = allgather_inplace(c, c->pos4[c->cur], sizeof(float4));
             tc_phase_end(c);
@@ -587,14 +662,11 @@ static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, do
     if ((rc = find_sph_quantities_nocheck(c, need_guess))) return rc;
     if ((rc = tc_launch_error(c))) return rc;
     double *fin = c->red + 4 * TC_RED_BLOCKS;
-    if (c->comm) {
+    if (c->comm || c->loop) {
         tc_phase_begin(c, PH_COMM);
-        g_rccl.GroupStart();
-        ncclResult_t r1 = g_rccl.AllReduce(fin, fin, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
-        ncclResult_t r2 = g_rccl.AllReduce(fin + 3, fin + 3, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream);
-        g_rccl.GroupEnd();
+        rc = allreduce_error_sums(c, fin);
         tc_phase_end(c);
-        if (r1 != ncclSuccess || r2 != ncclSuccess) TC_FAIL(c, TCGPU_ERR_COMM, "ncclAllReduce failed");
+        if (rc) return rc;
     }
     TC_HIP(c, hipMemcpyAsync(c->h_red, fin, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if ((rc = check_flags(c))) return rc;                     /* synchronises the stream */
@@ -607,7 +679,9 @@ extern "C" int tcgpu_density_error(tcgpu_ctx *c, double *err_mean, double *err_m
 {
     if (!c || c->n <= 0 || !c->have_model || !err_mean || !err_max) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
-    return density_error_sync(c, 1, err_mean, err_max);
+    int rc = density_error_sync(c, c->need_guess, err_mean, err_max);
+    if (!rc) c->need_guess = 0;
+    return rc;
 }
 
 /* src/wvt_relax.c:25-225: the loop, its step control and stop rules run on the host;
@@ -627,7 +701,8 @@ extern "C" int tcgpu_regularise_sph_particles(tcgpu_ctx *c, int max_iter, tcgpu_
         if (it++ >= numiter) break;                           /* wvt_relax.c:63-64 */
 
         double errMean = 0, errMax = 0;
-        if ((rc = density_error_sync(c, it == 0, &errMean, &errMax))) return rc;
+        if ((rc = density_error_sync(c, c->need_guess, &errMean, &errMax))) return rc;
+        c->need_guess = 0;
         errDiff = (errLast - errMean) / errMean;              /* wvt_relax.c:89 */
 
         if (log && nlog < TCGPU_MAXLOG) {
@@ -667,7 +742,7 @@ extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *
     TC_HIP(c, hipStreamSynchronize(c->stream));
     int rc = tc_launch_curl(c);
     if (rc) return rc;
-    if (c->comm) {
+    if (c->comm || c->loop) {
         tc_phase_begin(c, PH_COMM);
         rc = allgather_inplace(c, c->bfld, 3 * sizeof(float));
         tc_phase_end(c);
