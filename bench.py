@@ -134,6 +134,17 @@ def main():
     n_local = (n_total + world - 1) // world
     achieved = BYTES_DENSITY_PER_PARTICLE * n_local / dens_avg / 1e9 if dens_avg > 0 else 0.0
 
+    # HBM/fabric traffic of the dominant kernel: PMC counters cannot be collected from inside the
+    # process, so the figure measured by `tools/profile_round.sh` (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE passes of this same command) is read from profiles/ when present.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+    if os.path.exists(tpath) and world == 1 and args.particles_per_gpu == PER_GPU_PARTICLES:
+        try:
+            traffic = json.load(open(tpath))["bytes_per_launch"]
+        except Exception:
+            traffic = None
+
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline:
@@ -157,7 +168,7 @@ def main():
                        "particles_total": n_total, "parallelism": "peano-range shards x%d, RCCL all-gather" % world,
                        "err_mean_last": errs[-1][0], "err_max_last": errs[-1][1]},
             "roofline": {"bound": "hbm", "kernel": "k_density", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": 1e3 * dens_avg, "launches": dens_launch,
                          "algorithmic_bytes_per_particle": BYTES_DENSITY_PER_PARTICLE,
                          "whole_iteration_GBs": BYTES_ITER_PER_PARTICLE * n_total * args.steps / dt / 1e9 / world},
