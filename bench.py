@@ -13,7 +13,8 @@ Weak scaling: 2e6 particles per GPU; every rank solves its contiguous Peano rang
 exchange positions / smoothing lengths with RCCL all-gathers each iteration.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     -- dominant kernel (k_density): algorithmic bytes / measured kernel time vs HBM peak
+  roofline     -- dominant kernel (k_iter = fused density solve + WVT sweep): algorithmic bytes /
+                  measured kernel time vs HBM peak (the kernel is VALU-bound)
   cpu_baseline -- the CPU oracle ("port" of the reference algorithm, OpenMP) on a bounded sample
 """
 import argparse
@@ -28,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-BYTES_DENSITY_PER_PARTICLE = 28  # 12+4 B read, 12 B written per particle
+BYTES_DENSITY_PER_PARTICLE = 56  # K5 (12+4 R, 12 W) + K9 (12+4 R, 12 W), fused in k_iter
 BYTES_ITER_PER_PARTICLE = 868    # whole iteration incl. 128-bit radix sort
 PER_GPU_PARTICLES = 2_000_000
 
@@ -167,7 +168,7 @@ def main():
                                    "WVT iterations (sort + density solve + sweep + move)" % args.particles_per_gpu,
                        "particles_total": n_total, "parallelism": "peano-range shards x%d, RCCL all-gather" % world,
                        "err_mean_last": errs[-1][0], "err_max_last": errs[-1][1]},
-            "roofline": {"bound": "hbm", "kernel": "k_density", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_iter (fused density solve K5 + WVT sweep K9)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": 1e3 * dens_avg, "launches": dens_launch,
                          "algorithmic_bytes_per_particle": BYTES_DENSITY_PER_PARTICLE,

@@ -107,7 +107,9 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipMalloc(&c->norph, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->ngb_cnt, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->spill, sizeof(double) * (size_t)TC_MAX_PERSISTENT_BLOCKS * TC_WAVES_PER_BLOCK
-                                        * (TC_NGBMAX - TC_RCAP)) == hipSuccess;
+                                        * (2 * TC_NGBMAX)) == hipSuccess;
+    c->fuse = 1;
+    c->level_shift = 1;                          /* cells of h/4..h/2: fewest candidates per query (tools/fuse_stats.py) */
     ok = ok && hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess;
     ok = ok && hipMemset(c->flags, 0, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMemset(c->norph, 0, sizeof(int)) == hipSuccess;
@@ -126,7 +128,8 @@ static void free_particles(tcgpu_ctx *c)
     }
     hipFree(c->apot); hipFree(c->bfld); hipFree(c->key); hipFree(c->key_sorted); hipFree(c->idx);
     hipFree(c->idx_sorted); hipFree(c->sort_tmp); hipFree(c->cells); hipFree(c->guess);
-    hipFree(c->hwvt); hipFree(c->delta); hipFree(c->stats); hipFree(c->ngb_buf);
+    hipFree(c->hwvt); hipFree(c->delta); hipFree(c->stats); hipFree(c->ngb_buf); hipFree(c->ustep); hipFree(c->rhom_next);
+    c->ustep = nullptr; c->rhom_next = nullptr;
     c->apot = c->bfld = nullptr; c->key = c->key_sorted = nullptr; c->idx = c->idx_sorted = nullptr;
     c->sort_tmp = nullptr; c->cells = nullptr; c->guess = c->hwvt = c->delta = nullptr;
     c->stats = nullptr; c->ngb_buf = nullptr;
@@ -212,6 +215,8 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         TC_HIP(c, hipMalloc(&c->guess, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->hwvt, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->delta, 3 * cap * sizeof(float)));
+        TC_HIP(c, hipMalloc(&c->ustep, 3 * cap * sizeof(double)));
+        TC_HIP(c, hipMalloc(&c->rhom_next, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->stats, 4 * cap * sizeof(uint32_t)));
         TC_HIP(c, hipMalloc(&c->ngb_buf, cap * sizeof(int32_t)));
         c->cap = need;
@@ -269,6 +274,7 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
     TC_HIP(c, hipStreamSynchronize(c->stream));
     c->keys_valid = 0;
     c->index_valid = 0;
+    c->ustep_valid = 0;
     c->need_guess = 1;
     if (hsml) {                                   /* warm start: the guess is only read where hsml == 0 */
         c->need_guess = 0;
@@ -458,6 +464,7 @@ extern "C" int tcgpu_sort_particles_by_peano_key(tcgpu_ctx *c)
     if ((rc = tc_launch_permute(c))) return rc;
     c->keys_valid = 1;
     c->index_valid = 0;
+    c->ustep_valid = 0;
     return TCGPU_OK;
 }
 
@@ -533,13 +540,19 @@ static int density_stats(tcgpu_ctx *c)
     return 0;
 }
 
-static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess)
+static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess, int with_wvt)
 {
     int rc;
     if ((rc = tcgpu_sort_particles_by_peano_key(c))) return rc;
     if ((rc = tc_launch_cells(c))) return rc;
     if (need_guess && (rc = tc_launch_guess(c))) return rc;
-    if ((rc = tc_launch_density(c))) return rc;
+    if (c->fuse && !c->ablate) {
+        /* one gather per particle serves the density solve and (with_wvt) the WVT sweep that
+         * follows on the same positions; the sweep needs the model hsml up front */
+        if (with_wvt && (rc = tc_launch_model_hsml(c))) return rc;
+        if ((rc = tc_launch_iter(c, with_wvt))) return rc;
+        c->ustep_valid = with_wvt;
+    } else if ((rc = tc_launch_density(c))) return rc;
     if (c->comm || c->loop) {
         tc_phase_begin(c, PH_COMM);
         if (c->comm) g_rccl.GroupStart();
@@ -557,7 +570,7 @@ extern "C" int tcgpu_find_sph_quantities(tcgpu_ctx *c)
 {
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
-    int rc = find_sph_quantities_nocheck(c, c->need_guess);
+    int rc = find_sph_quantities_nocheck(c, c->need_guess, 0);
     if (rc) return rc;
     rc = check_flags(c);
     if (rc) return rc;
@@ -625,8 +638,14 @@ extern "C" int tcgpu_find_ngb(tcgpu_ctx *c, int64_t ipart, float hsml, int32_t *
 static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
 {
     int rc;
-    if ((rc = tc_launch_model_hsml(c))) return rc;
-    if ((rc = tc_launch_wvt(c, step))) return rc;
+    if (c->ustep_valid) {                         /* the fused pass already summed the sweep for unit step */
+        if ((rc = tc_launch_commit_rhom(c))) return rc;
+        if ((rc = tc_launch_apply_step(c, step))) return rc;
+    } else {
+        if ((rc = tc_launch_model_hsml(c))) return rc;
+        if ((rc = tc_launch_commit_rhom(c))) return rc;
+        if ((rc = tc_launch_wvt(c, step))) return rc;
+    }
     if (move) {
         if ((rc = tc_launch_move(c))) return rc;
         if (c->comm || c->loop) {
@@ -659,7 +678,7 @@ extern "C" int tcgpu_wvt_step(tcgpu_ctx *c, double step, float *hsml_wvt, float 
 static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, double *err_max)
 {
     int rc;
-    if ((rc = find_sph_quantities_nocheck(c, need_guess))) return rc;
+    if ((rc = find_sph_quantities_nocheck(c, need_guess, 1))) return rc;
     if ((rc = tc_launch_error(c))) return rc;
     double *fin = c->red + 4 * TC_RED_BLOCKS;
     if (c->comm || c->loop) {
@@ -763,6 +782,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "timing")) c->timing = value != 0;
     else if (!strcmp(name, "level_shift")) c->level_shift = (int)value;
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
+    else if (!strcmp(name, "fuse")) c->fuse = value != 0;
     else if (!strcmp(name, "force_comm")) c->force_comm = value != 0;   /* tests: 1-rank RCCL communicator */
     else if (!strcmp(name, "lmax")) {
         if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "lmax must be set before tcgpu_upload_particles");

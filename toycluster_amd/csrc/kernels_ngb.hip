@@ -101,13 +101,14 @@ struct tc_query {
     int L, nL;            /* level, cells per dimension */
     int lo[3], nd[3];     /* first cell (unwrapped, may be negative) and cell count per dim */
     bool full[3];         /* the dimension covers the whole ring: no culling there */
-    double s, hp;         /* cell edge, padded radius */
+    float sf, hpf;        /* cell edge and padded radius (f32 copies for the per-cell culling) */
+    float inv_nyz, inv_nz;
     size_t off;           /* table offset of the level */
 };
 
 __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, float yi, float zi, float h, tc_query &q)
 {
-    /* level with s < h <= 2s : L = floor(log2(box/h)) + 1 */
+    /* level with s < h <= 2s : L = floor(log2(box/h)) + 1 (+ level_shift) */
     double ratio = k.boxsize / (double)h;
     int L = (ratio >= 1.0) ? (ilogb(ratio) + 1) : 1;
     L += k.level_shift;
@@ -115,24 +116,29 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
     if (L > k.lmax) L = k.lmax;
     q.L = L;
     q.nL = 1 << L;
-    q.s = k.boxsize / (double)q.nL;
+    const double s = k.boxsize / (double)q.nL;
     const double inv_s = (double)q.nL / k.boxsize;
     q.off = tc_level_offset(L);
-    /* pad: the f32 predicate can accept pairs a few ulp beyond h */
-    q.hp = (double)h * (1.0 + 1e-5) + k.boxsize * 1e-7;
+    /* pad: the f32 predicate can accept pairs a few ulp beyond h, and the per-cell culling below
+     * runs in f32 on coordinates of magnitude boxsize (absolute error < 3e-7 boxsize) */
+    const double hp = (double)h * (1.0 + 1e-5) + k.boxsize * 2e-6;
+    q.sf = (float)s;
+    q.hpf = (float)hp;
     const float xs[3] = {xi, yi, zi};
-    const bool huge = !(q.hp < k.boxsize);      /* ball wider than the box: take every cell once */
+    const bool huge = !(hp < k.boxsize);      /* ball wider than the box: take every cell once */
     for (int d = 0; d < 3; d++) {
         int lo = 0, nd = q.nL;
         if (!huge) {
-            lo = (int)floor(((double)xs[d] - q.hp) * inv_s);     /* margins in hp absorb the rounding */
-            int hi = (int)floor(((double)xs[d] + q.hp) * inv_s);
+            lo = (int)floor(((double)xs[d] - hp) * inv_s);     /* margins in hp absorb the rounding */
+            int hi = (int)floor(((double)xs[d] + hp) * inv_s);
             nd = hi - lo + 1;
         }
         q.full[d] = false;
         if (nd >= q.nL) { nd = q.nL; lo = 0; q.full[d] = true; }
         q.lo[d] = lo; q.nd[d] = nd;
     }
+    q.inv_nyz = 1.0f / (float)(q.nd[1] * q.nd[2]);
+    q.inv_nz = 1.0f / (float)q.nd[2];
 }
 
 /* Per-lane cell c of the query block: returns the particle run [st,en) (empty if culled). */
@@ -140,24 +146,35 @@ __device__ __forceinline__ void query_cell(const tc_dev_const &k, const tc_query
                                            int c, uint32_t &st, uint32_t &en)
 {
     st = en = 0;
-    int nyz = q.nd[1] * q.nd[2];
-    int a = c / nyz, r = c - a * nyz;
-    int b = r / q.nd[2], cc = r - b * q.nd[2];
+    /* c -> (a, b, cc) without integer division: (c + 0.5)/n is never within 0.5/n of an integer,
+     * far more than the rounding of the reciprocal multiply (valid while the block has < 2^22 cells) */
+    const int nyz = q.nd[1] * q.nd[2];
+    int a, b, cc;
+    if (q.nd[0] * nyz < (1 << 22)) {
+        a = (int)(((float)c + 0.5f) * q.inv_nyz);
+        int r = c - a * nyz;
+        b = (int)(((float)r + 0.5f) * q.inv_nz);
+        cc = r - b * q.nd[2];
+    } else {
+        a = c / nyz;
+        int r = c - a * nyz;
+        b = r / q.nd[2];
+        cc = r - b * q.nd[2];
+    }
     const int off[3] = {a, b, cc};
     const float xs[3] = {xi, yi, zi};
-    double g2 = 0;
+    float g2 = 0;
     size_t lin = 0;
     for (int d = 0; d < 3; d++) {
         int u = q.lo[d] + off[d];                 /* unwrapped cell coordinate */
         if (!q.full[d]) {
-            double clo = (double)u * q.s, chi = clo + q.s;
-            double x = (double)xs[d];
-            double g = x < clo ? clo - x : (x > chi ? x - chi : 0.0);
+            float clo = (float)u * q.sf, chi = clo + q.sf;
+            float g = xs[d] < clo ? clo - xs[d] : (xs[d] > chi ? xs[d] - chi : 0.0f);
             g2 += g * g;
         }
         lin = lin * (size_t)q.nL + (size_t)(u & (q.nL - 1));
     }
-    if (g2 > q.hp * q.hp) return;
+    if (g2 > q.hpf * q.hpf) return;
     uint2 ce = k.cells[q.off + lin];            /* {~first, last+1}, both 0 when empty */
     uint32_t s0 = ~ce.x, e0 = ce.y;
     if (e0 > s0) { st = s0; en = e0; }
@@ -206,7 +223,7 @@ __device__ __forceinline__ bool consume_candidates(const tc_dev_const &k, const 
  */
 template <class Body>
 __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, float xi, float yi, float zi, float h,
-                                                      uint32_t *idx, Body &&body)
+                                                      uint32_t *idx, uint32_t idxcap, Body &&body)
 {
     const int lane = lane_id();
     tc_query q;
@@ -232,11 +249,11 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
             ncand += c0;
             uint32_t done = 0;
             while (done < c0) {
-                uint32_t take = min(c0 - done, (uint32_t)TC_IDXCAP - fill);
+                uint32_t take = min(c0 - done, idxcap - fill);
                 for (uint32_t t = lane; t < take; t += 64) idx[fill + t] = s0 + done + t;
                 fill += take;
                 done += take;
-                if (fill == TC_IDXCAP) {
+                if (fill == idxcap) {
                     wave_lds_fence();
                     if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
                     wave_lds_fence();
@@ -250,7 +267,7 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
         while (__ballot(pend > 0)) {
             uint32_t incl = wave_incl_scan(pend);
             uint32_t excl = incl - pend;
-            bool ok = pend > 0 && incl <= (uint32_t)TC_IDXCAP - fill;
+            bool ok = pend > 0 && incl <= idxcap - fill;
             if (ok)
                 for (uint32_t t = 0; t < pend; t++) idx[fill + excl + t] = st + t;
             uint64_t okm = __ballot(ok);
@@ -320,14 +337,23 @@ struct tc_density_args {
 
 /* the hit list: r (f64) of every neighbour found by the last ball query */
 struct tc_rlist {
-    double *lds;               /* TC_RCAP entries */
-    double *spill;             /* TC_NGBMAX - TC_RCAP entries */
-    __device__ __forceinline__ double get(int kk) const { return kk < TC_RCAP ? lds[kk] : spill[kk - TC_RCAP]; }
+    double *lds;               /* `cap` entries */
+    double *spill;             /* TC_NGBMAX entries (slot kk >= cap lives at spill[kk - cap]) */
+    int cap;
+    __device__ __forceinline__ double get(int kk) const { return kk < cap ? lds[kk] : spill[kk - cap]; }
     __device__ __forceinline__ void put(int kk, double v) const
     {
-        if (kk < TC_RCAP) lds[kk] = v;
-        else spill[kk - TC_RCAP] = v;
+        if (kk < cap) lds[kk] = v;
+        else spill[kk - cap] = v;
     }
+};
+
+/* two-part hit list of the fused kernel: neighbours inside the carried hsml ("inner") and the shell
+ * out to 1.23 hsml ("outer"); as one list, inner entries come first */
+struct tc_list2 {
+    tc_rlist in, out;
+    int cs;                    /* inner count: get(kk) switches lists there */
+    __device__ __forceinline__ double get(int kk) const { return kk < cs ? in.get(kk) : out.get(kk - cs); }
 };
 
 /* ring of staged hit positions (and hsml_wvt for the sweep), TC_STAGE entries per wave */
@@ -343,7 +369,8 @@ __device__ __attribute__((noinline)) double bisect_hsml(double lower, double upp
 }
 
 /* src/sph.c:80-214 on the hit list.  All lanes return identical values. */
-__device__ __forceinline__ bool solve_hsml(const tc_rlist &rl, int cnt, double mpart, double bias_const,
+template <class List>
+__device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart, double bias_const,
                                            float &hsml_io, float &rho_out, float &drho_io,
                                            uint32_t &iters, uint32_t &pairs)
 {
@@ -444,32 +471,28 @@ __device__ __forceinline__ bool solve_hsml(const tc_rlist &rl, int cnt, double m
     return part_done;
 }
 
-/* src/sph.c:21-71 for particle i */
-__device__ __forceinline__ void density_one(const tc_density_args &a, int i, const tc_rlist &rl, uint32_t *idx,
-                                            const tc_stage &st)
+/* per-particle state of the loop of src/sph.c:36-64 */
+struct tc_dstate {
+    float hsml, rho, dRhodHsml;
+    uint32_t nq, nit, npair, ncand;
+    bool ok;
+};
+
+/* src/sph.c:36-64 from the hsml in `d` on: ball query, raw-count guards, Find_hsml, until done */
+__device__ __forceinline__ void density_loop(const tc_density_args &a, int i, float xi, float yi, float zi,
+                                             const tc_rlist &rl, uint32_t *idx, uint32_t idxcap, const tc_stage &st,
+                                             tc_dstate &d)
 {
     const tc_dev_const &k = a.k;
     const int lane = lane_id();
-    const float4 pi = k.pos4[i];
-    const float xi = pi.x, yi = pi.y, zi = pi.z;
-    float hsml = a.hsml_in[i];
-    if (hsml == 0) hsml = 2 * a.guess[i];                 /* src/sph.c:25-26 */
-    if (!isfinite(hsml)) {                                /* src/sph.c:28 */
-        if (lane == 0) atomicOr(&a.flags[0], 1);
-        return;
-    }
-
-    float dRhodHsml = 0, rho = 0;
-    uint32_t nq = 0, nit = 0, npair = 0, ncand = 0;
-    bool ok = false;
-
+    float hsml = d.hsml;
     for (int guard = 0; guard < 4096; guard++) {
         /* ---- ball query (src/tree.c:25-111), f32 predicate, list capped at NGBMAX.
          * Hits (about a third of the candidates) are first compacted into a 128-entry LDS ring of
          * positions; the f64 pair distance is evaluated 64 hits at a time with every lane busy. */
         const float h2 = hsml * hsml;
         int cnt = 0, scnt = 0, head = 0;
-        nq++;
+        d.nq++;
         auto convert = [&](int nvalid) {
             wave_lds_fence();
             int sl = (head + lane) & (TC_STAGE - 1);
@@ -482,7 +505,7 @@ __device__ __forceinline__ void density_one(const tc_density_args &a, int i, con
             head = U((head + 64) & (TC_STAGE - 1));
             wave_lds_fence();
         };
-        ncand += stream_candidates(k, xi, yi, zi, hsml, idx, [&](int j, float4 p, bool act) -> bool {
+        d.ncand += stream_candidates(k, xi, yi, zi, hsml, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
             float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2 < h2);
             uint64_t m = __ballot(hit);
@@ -500,31 +523,57 @@ __device__ __forceinline__ void density_one(const tc_density_args &a, int i, con
         cnt = U(cnt);
         wave_lds_fence();
         if (k.ablate) {
-            if (k.ablate != 3 || cnt >= TC_DESNNGB) { ok = true; break; }
+            if (k.ablate != 3 || cnt >= TC_DESNNGB) { d.ok = true; break; }
             hsml = (float)((double)hsml * 1.23);
             continue;
         }
         if (cnt >= TC_NGBMAX) { hsml = (float)((double)hsml / 1.24); continue; }   /* src/sph.c:42-47 */
         if (cnt < TC_DESNNGB) { hsml = (float)((double)hsml * 1.23); continue; }   /* src/sph.c:49-54 */
 
-        if (solve_hsml(rl, cnt, k.mpart, a.bias_const, hsml, rho, dRhodHsml, nit, npair)) { ok = true; break; }
+        if (solve_hsml(rl, cnt, k.mpart, a.bias_const, hsml, d.rho, d.dRhodHsml, d.nit, d.npair)) { d.ok = true; break; }
         if (!isfinite(hsml)) break;
     }
-    if (!ok) {
-        if (lane == 0) atomicOr(&a.flags[2], 1);
+    d.hsml = hsml;
+}
+
+/* src/sph.c:66-70 */
+__device__ __forceinline__ void density_store(const tc_density_args &a, int i, const tc_dstate &d)
+{
+    if (lane_id() != 0) return;
+    if (!d.ok) atomicOr(&a.flags[2], 1);
+    float varHsmlFac = (float)(1.0 / (double)(1 + d.hsml / (3 * d.rho) * d.dRhodHsml));
+    a.hsml_out[i] = d.hsml;
+    a.rho_out[i] = d.rho;
+    a.vhf_out[i] = varHsmlFac;
+    if (a.stats) {
+        a.stats[i] = d.nq;
+        a.stats[i + (size_t)a.stats_stride] = d.nit;
+        a.stats[i + 2 * (size_t)a.stats_stride] = d.npair;
+        a.stats[i + 3 * (size_t)a.stats_stride] = d.ncand;
     }
-    if (lane == 0) {
-        float varHsmlFac = (float)(1.0 / (double)(1 + hsml / (3 * rho) * dRhodHsml));   /* src/sph.c:66 */
-        a.hsml_out[i] = hsml;
-        a.rho_out[i] = rho;
-        a.vhf_out[i] = varHsmlFac;
-        if (a.stats) {
-            a.stats[i] = nq;
-            a.stats[i + (size_t)a.stats_stride] = nit;
-            a.stats[i + 2 * (size_t)a.stats_stride] = npair;
-            a.stats[i + 3 * (size_t)a.stats_stride] = ncand;
-        }
+}
+
+/* src/sph.c:21-71 for particle i.  Returns false when hsml is not finite (src/sph.c:28). */
+__device__ __forceinline__ bool density_init(const tc_density_args &a, int i, tc_dstate &d)
+{
+    d.rho = 0; d.dRhodHsml = 0; d.nq = d.nit = d.npair = d.ncand = 0; d.ok = false;
+    d.hsml = a.hsml_in[i];
+    if (d.hsml == 0) d.hsml = 2 * a.guess[i];                 /* src/sph.c:25-26 */
+    if (!isfinite(d.hsml)) {                                  /* src/sph.c:28 */
+        if (lane_id() == 0) atomicOr(&a.flags[0], 1);
+        return false;
     }
+    return true;
+}
+
+__device__ __forceinline__ void density_one(const tc_density_args &a, int i, const tc_rlist &rl, uint32_t *idx,
+                                            const tc_stage &st)
+{
+    const float4 pi = a.k.pos4[i];
+    tc_dstate d;
+    if (!density_init(a, i, d)) return;
+    density_loop(a, i, pi.x, pi.y, pi.z, rl, idx, TC_IDXCAP, st, d);
+    density_store(a, i, d);
 }
 
 #define TC_LDS_PER_WAVE_DENSITY (TC_RCAP * sizeof(double) + TC_IDXCAP * sizeof(uint32_t) + 3 * TC_STAGE * sizeof(float))
@@ -538,7 +587,8 @@ __global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
     const int gw = blockIdx.x * WPB + wave;
     tc_rlist rl;
     rl.lds = reinterpret_cast<double *>(mine);
-    rl.spill = a.spill + (size_t)gw * (TC_NGBMAX - TC_RCAP);
+    rl.spill = a.spill + (size_t)gw * (2 * TC_NGBMAX);
+    rl.cap = TC_RCAP;
     uint32_t *idx = reinterpret_cast<uint32_t *>(mine + TC_RCAP * sizeof(double));
     tc_stage st;
     st.x = reinterpret_cast<float *>(idx + TC_IDXCAP);
@@ -649,17 +699,17 @@ __device__ __forceinline__ void wvt_pair(const float4 pi, const float4 pj, doubl
     d2 = fma(base, (double)dz, d2);
 }
 
-__device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *idx, const tc_stage &st)
+/* src/wvt_relax.c:128-171 for particle i: sum of step_hi * W6 * unit(r_ij) over the ball of radius hq */
+__device__ __forceinline__ void wvt_sum(const tc_dev_const &k, int i, const float4 pi, double step_hi, int *flags,
+                                        uint32_t *idx, uint32_t idxcap, const tc_stage &st, double &d0, double &d1,
+                                        double &d2)
 {
     const int lane = lane_id();
-    const tc_dev_const &k = a.k;
-    const float4 pi = k.pos4[i];
     const double boxinv = 1 / k.boxsize;
     const float hq = (float)((double)pi.w * k.boxsize);      /* src/wvt_relax.c:135 */
     const float hq2 = hq * hq;
-    const double step_hi = a.step * (double)pi.w;
 
-    double d0 = 0, d1 = 0, d2 = 0;
+    d0 = d1 = d2 = 0;
     int cnt = 0, scnt = 0, head = 0;
     /* hits are compacted into the LDS ring first so that the pair arithmetic runs on full waves */
     auto convert = [&](int nvalid) {
@@ -670,7 +720,7 @@ __device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *i
         head = U((head + 64) & (TC_STAGE - 1));
         wave_lds_fence();
     };
-    stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
+    stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
         float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
         bool hit = act && (r2 < hq2);
         cnt += __popcll(__ballot(hit));
@@ -690,12 +740,12 @@ __device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *i
         /* The reference truncates the list to the first NGBMAX hits in ascending index
          * (src/tree.c:91-92).  Find the index threshold T with exactly NGBMAX hits below it
          * by bisection over re-gathers, then redo the sum with j < T.  Never seen in practice. */
-        if (lane == 0) atomicAdd(&a.flags[4], 1);
+        if (lane == 0) atomicAdd(&flags[4], 1);
         int tlo = 0, thi = k.n;                      /* count(j < tlo) < NGBMAX <= count(j < thi) */
         while (thi - tlo > 1) {
             int mid = tlo + ((thi - tlo) >> 1);
             int cm = 0;
-            stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
+            stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
                 float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
                 cm += __popcll(__ballot(act && (r2 < hq2) && j < mid));
                 return false;
@@ -703,15 +753,21 @@ __device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *i
             if (cm >= TC_NGBMAX) thi = mid; else tlo = mid;
         }
         d0 = d1 = d2 = 0;
-        stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
+        stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
             float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             if (act && (r2 < hq2) && j < thi && j != i) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
             return false;
         });
     }
-
     d0 = wsum(d0); d1 = wsum(d1); d2 = wsum(d2);
-    if (lane == 0) {
+}
+
+__device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *idx, const tc_stage &st)
+{
+    const float4 pi = a.k.pos4[i];
+    double d0, d1, d2;
+    wvt_sum(a.k, i, pi, a.step * (double)pi.w, a.flags, idx, TC_IDXCAP, st, d0, d1, d2);
+    if (lane_id() == 0) {
         a.delta[3 * (size_t)i] = (float)d0;
         a.delta[3 * (size_t)i + 1] = (float)d1;
         a.delta[3 * (size_t)i + 2] = (float)d2;
@@ -749,6 +805,187 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
     return 0;
 }
 
+/* ------------------------------------------------------------------ fused K5 + K9: one gather per particle */
+
+/*
+ * The reference queries the ball of the carried hsml, very often finds fewer than 295 raw
+ * neighbours, retries at 1.23 hsml (src/sph.c:49-54), and later queries a third, almost equal ball
+ * for the WVT sweep (src/wvt_relax.c:135).  On warm iterations this kernel gathers ONCE at
+ * R = max(1.23 hsml, hsml_wvt*box) and keeps for every hit its f32 r2, which is all the reference's
+ * predicates look at: the list of the first query is {r2 < hsml^2} ("inner"), the list of the retry
+ * is inner + {r2 < (1.23 hsml)^2} ("outer"), the sweep's list is {r2 < (hsml_wvt*box)^2}.  The
+ * reference's control flow then runs on exactly those lists.  Anything unusual (cold start, NGBMAX
+ * overflow, a third query) falls back to the plain per-query code above.
+ * The sweep is accumulated for unit step: the step size is decided by the host from this very
+ * pass's error sums (src/wvt_relax.c:89-101); k_move applies delta = step * U.
+ */
+struct tc_iter_args {
+    tc_density_args d;
+    double *ustep;             /* 3n, unit-step displacement sums; NULL => density only */
+};
+
+#define TC_ICAP 512            /* inner entries in LDS */
+#define TC_OCAP 384            /* outer entries in LDS */
+#define TC_ITER_IDXCAP 512
+#define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 5 * TC_STAGE * sizeof(float))
+
+__device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
+{
+    const tc_density_args &da = a.d;
+    const tc_dev_const &k = da.k;
+    const int lane = lane_id();
+    const float4 pi = k.pos4[i];
+    const float xi = pi.x, yi = pi.y, zi = pi.z;
+    const bool do_wvt = a.ustep != nullptr;
+
+    double *lds_lists = reinterpret_cast<double *>(mine);
+    uint32_t *idx = reinterpret_cast<uint32_t *>(lds_lists + TC_ICAP + TC_OCAP);
+    tc_stage st;
+    st.x = reinterpret_cast<float *>(idx + TC_ITER_IDXCAP);
+    st.y = st.x + TC_STAGE; st.z = st.y + TC_STAGE; st.w = st.z + TC_STAGE;
+    float *st_r2 = st.w + TC_STAGE;
+    const uint32_t idxcap = TC_ITER_IDXCAP;
+    tc_rlist plain;                                   /* the fallback path sees one list over both LDS parts */
+    plain.lds = lds_lists; plain.spill = spill; plain.cap = TC_ICAP + TC_OCAP;
+
+    tc_dstate d;
+    const bool finite = density_init(da, i, d);
+    const bool warm = finite && da.hsml_in[i] != 0;
+    double u0 = 0, u1 = 0, u2 = 0;
+    bool wvt_done = false;
+
+    if (warm) {
+        const float h0 = d.hsml;
+        const float hb = (float)((double)h0 * 1.23);
+        const float h0sq = h0 * h0, hbsq = hb * hb;
+        const float hw = (float)((double)pi.w * k.boxsize);          /* src/wvt_relax.c:135 */
+        const float hwsq = hw * hw;
+        const float R = (do_wvt && hw > hb) ? hw : hb;
+        const float Rsq = R * R;
+        const double boxinv = 1 / k.boxsize;
+        const double step_hi = (double)pi.w;                          /* unit step */
+
+        tc_list2 L;
+        L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
+        L.out.lds = lds_lists + TC_ICAP; L.out.spill = spill + TC_NGBMAX;  L.out.cap = TC_OCAP;
+        int cs = 0, co = 0, cw = 0, scnt = 0, head = 0;
+
+        auto convert = [&](int nvalid) {
+            wave_lds_fence();
+            int sl = (head + lane) & (TC_STAGE - 1);
+            float4 p = make_float4(st.x[sl], st.y[sl], st.z[sl], st.w[sl]);
+            float r2 = st_r2[sl];                                      /* sign bit set <=> the particle itself */
+            const bool valid = lane < nvalid;
+            const bool dens = valid && (r2 < hbsq);
+            const bool inn = dens && (r2 < h0sq);
+            const bool outr = dens && !inn;
+            double r = 0;
+            if (dens) r = tc_pair_r(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize);
+            const uint64_t m_in = __ballot(inn), m_out = __ballot(outr);
+            if (inn) { int slot = cs + mask_rank(m_in); if (slot < TC_NGBMAX) L.in.put(slot, r); }
+            if (outr) { int slot = co + mask_rank(m_out); if (slot < TC_NGBMAX) L.out.put(slot, r); }
+            cs = U(cs + (int)__popcll(m_in));
+            co = U(co + (int)__popcll(m_out));
+            if (do_wvt) {
+                const bool wv = valid && (r2 < hwsq);
+                cw = U(cw + (int)__popcll(__ballot(wv)));
+                if (wv && !signbit(r2)) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2);
+            }
+            head = U((head + 64) & (TC_STAGE - 1));
+            wave_lds_fence();
+        };
+        d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
+            float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+            bool hit = act && (r2 < Rsq);
+            uint64_t m = __ballot(hit);
+            if (hit) {
+                int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
+                st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = p.w;
+                st_r2[sl] = (j == i) ? -r2 : r2;                       /* r2 == 0 for the particle itself: -0.0f */
+            }
+            scnt = U(scnt + (int)__popcll(m));
+            if (scnt >= 64) { convert(64); scnt = U(scnt - 64); }
+            return cs + co >= TC_NGBMAX;
+        });
+        if (cs + co < TC_NGBMAX && scnt > 0) convert(scnt);
+        wave_lds_fence();
+        const int ca = cs + co;
+
+        if (ca < TC_NGBMAX) {
+            if (do_wvt && cw < TC_NGBMAX) {
+                u0 = wsum(u0); u1 = wsum(u1); u2 = wsum(u2);
+                wvt_done = true;
+            }
+            /* src/sph.c:36-64 on the two virtual queries */
+            bool solved = false;
+            if (cs >= TC_DESNNGB) {                                    /* first query already has >= 295 */
+                d.nq += 1;
+                L.cs = cs;
+                solved = solve_hsml(L, cs, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair);
+            } else {                                                   /* hsml *= 1.23, second query */
+                d.nq += 2;
+                d.hsml = hb;
+                if (ca >= TC_DESNNGB) {
+                    L.cs = cs;
+                    solved = solve_hsml(L, ca, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair);
+                } else {
+                    d.hsml = (float)((double)hb * 1.23);               /* still too few: third query, plain path */
+                }
+            }
+            if (solved) d.ok = true;
+        }
+        /* ca >= NGBMAX: the first or second query of the reference would have overflowed its list;
+         * replay it exactly from the carried hsml with the plain code */
+    }
+
+    if (finite && !d.ok && isfinite(d.hsml)) density_loop(da, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d);
+    if (finite) density_store(da, i, d);
+
+    if (do_wvt) {
+        if (!wvt_done) wvt_sum(k, i, pi, (double)pi.w, da.flags, idx, TC_ITER_IDXCAP, st, u0, u1, u2);
+        if (lane == 0) {
+            a.ustep[3 * (size_t)i] = u0;
+            a.ustep[3 * (size_t)i + 1] = u1;
+            a.ustep[3 * (size_t)i + 2] = u2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TBN) void k_iter(tc_iter_args a)
+{
+    __shared__ __align__(16) unsigned char lds_raw[WPB * TC_LDS_PER_WAVE_ITER];
+    const int wave = threadIdx.x >> 6;
+    unsigned char *mine = lds_raw + (size_t)wave * TC_LDS_PER_WAVE_ITER;
+    const int gw = blockIdx.x * WPB + wave;
+    double *spill = a.d.spill + (size_t)gw * (2 * TC_NGBMAX);
+    const tc_stride ws = wave_stride(a.d.k.lo, a.d.k.hi, wave);
+    for (int i = ws.first; i < ws.end; i += ws.step) iter_one(a, i, mine, spill);
+}
+
+int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
+{
+    tc_iter_args a;
+    tc_fill_const(c, &a.d.k);
+    a.d.hsml_in = c->hsml[c->cur];
+    a.d.guess = c->guess;
+    a.d.hsml_out = c->hsml[c->cur];
+    a.d.rho_out = c->rho[c->cur];
+    a.d.vhf_out = c->vhf[c->cur];
+    a.d.bias_const = -0.0116 * pow(TC_DESNNGB * 0.01, -2.236);   /* src/sph.c:206 */
+    a.d.spill = c->spill;
+    a.d.flags = c->flags;
+    a.d.stats = c->want_stats ? c->stats : nullptr;
+    a.d.stats_stride = (int)c->cap;
+    a.ustep = with_wvt ? c->ustep : nullptr;
+    int nloc = a.d.k.hi - a.d.k.lo;
+    if (nloc <= 0) return 0;
+    tc_phase_begin(c, PH_DENSITY);
+    k_iter<<<grid_for(c, nloc, k_iter), TBN, 0, c->stream>>>(a);
+    tc_phase_end(c);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
 /* ------------------------------------------------------------------ K11 curl(A) */
 
 struct tc_curl_args {
@@ -761,6 +998,7 @@ struct tc_curl_args {
 /* src/sph.c:224-295 for particle i */
 __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t *idx)
 {
+    const uint32_t idxcap = TC_IDXCAP;
     const int lane = lane_id();
     const tc_dev_const &k = a.k;
     const float4 pi = k.pos4[i];
@@ -776,7 +1014,7 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
 
     for (int pass = 0; pass < 2; pass++) {
         cnt = 0; b0 = b1 = b2 = 0;
-        stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
+        stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
             float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2f < hq2) && j < thi;
             cnt += __popcll(__ballot(hit));
@@ -810,7 +1048,7 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
         while (thi - tlo > 1) {
             int mid = tlo + ((thi - tlo) >> 1);
             int cm = 0;
-            stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, [&](int j, float4 p, bool act) -> bool {
+            stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
                 float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
                 cm += __popcll(__ballot(act && (r2f < hq2) && j < mid));
                 return false;
@@ -858,10 +1096,11 @@ int tc_launch_curl(tcgpu_ctx *c)
 __global__ __launch_bounds__(64) void k_find_ngb(tc_dev_const k, int i, float hsml, int32_t *out, int *count)
 {
     __shared__ __align__(16) uint32_t idx[TC_IDXCAP];
+    const uint32_t idxcap = TC_IDXCAP;
     const float4 pi = k.pos4[i];
     const float h2 = hsml * hsml;
     int cnt = 0;
-    stream_candidates(k, pi.x, pi.y, pi.z, hsml, idx, [&](int j, float4 p, bool act) -> bool {
+    stream_candidates(k, pi.x, pi.y, pi.z, hsml, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
         float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
         bool hit = act && (r2 < h2);
         uint64_t m = __ballot(hit);

@@ -395,10 +395,42 @@ int tc_launch_model_hsml(tcgpu_ctx *c)
     int n = (int)c->n, nb = TC_RED_BLOCKS;
     double *fin = c->red + 4 * TC_RED_BLOCKS + 4;
     tc_phase_begin(c, PH_MODEL_HSML);
+    /* Rho_Model goes to a side buffer: the reference stores it when the sweep runs (wvt_relax.c:113),
+     * so it is committed by tc_launch_commit_rhom(), not on iterations that stop before the sweep */
     k_model_hsml<<<nb, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize * 0.5, c->par.mpart_gas, c->d_halo,
-                                           c->par.nhalos, c->rhom[c->cur], c->hwvt, c->red);
+                                           c->par.nhalos, c->rhom_next, c->hwvt, c->red);
     k_final4<<<1, TB, 0, c->stream>>>(c->red, nb, fin);
     k_scale_hsml<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, fin, c->hwvt);
+    tc_phase_end(c);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int tc_launch_commit_rhom(tcgpu_ctx *c)
+{
+    TC_HIP(c, hipMemcpyAsync(c->rhom[c->cur], c->rhom_next, (size_t)c->n * sizeof(float), hipMemcpyDeviceToDevice,
+                             c->stream));
+    return 0;
+}
+
+/* delta = step * U for the fused kernel's unit-step sums (src/wvt_relax.c:167-169 with the scalar
+ * step factored out of the neighbour sum) */
+__global__ __launch_bounds__(TB) void k_apply_step(const double *__restrict__ ustep, float *__restrict__ delta,
+                                                   int lo, int hi, double step)
+{
+    int i = lo + blockIdx.x * TB + threadIdx.x;
+    if (i >= hi) return;
+    for (int c = 0; c < 3; c++) delta[3 * (size_t)i + c] = (float)(step * ustep[3 * (size_t)i + c]);
+}
+
+int tc_launch_apply_step(tcgpu_ctx *c, double step)
+{
+    int lo = (int)(c->rank * c->shard_len), hi = (int)((c->rank + 1) * c->shard_len);
+    if (hi > c->n) hi = (int)c->n;
+    if (lo > hi) lo = hi;
+    tc_phase_begin(c, PH_WVT);
+    if (hi > lo)
+        k_apply_step<<<(hi - lo + TB - 1) / TB, TB, 0, c->stream>>>(c->ustep, c->delta, lo, hi, step);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -440,5 +472,6 @@ int tc_launch_move(tcgpu_ctx *c)
     TC_HIP(c, hipGetLastError());
     c->keys_valid = 0;
     c->index_valid = 0;
+    c->ustep_valid = 0;
     return 0;
 }

@@ -78,7 +78,11 @@ struct tcgpu_ctx {
     int lmax, lmax_alloc;
     uint2 *cells;
     size_t ncells_alloc;
-    double *spill;                /* TC_MAX_PERSISTENT_BLOCKS*WPB x (NGBMAX-TC_RCAP) */
+    double *spill;                /* TC_MAX_PERSISTENT_BLOCKS*WPB x 2*NGBMAX */
+    double *ustep;                /* 3*cap: unit-step WVT displacement sums of the fused kernel */
+    float *rhom_next;             /* cap: model density at the current positions, committed by the sweep */
+    int ustep_valid;              /* ustep/rhom_next/hwvt belong to the current order and positions */
+    int fuse;                     /* option: use the fused kernel (default 1) */
     int num_cu;
     uint32_t *orphans;
     int *norph;
@@ -146,7 +150,10 @@ int tc_launch_model(tcgpu_ctx *c, float *d_out);
 int tc_launch_error(tcgpu_ctx *c);              /* -> red[0..2] = sum err, count, max err (over the shard) */
 int tc_launch_model_hsml(tcgpu_ctx *c);         /* rhom, hwvt (normalised, also into pos4.w) */
 int tc_launch_move(tcgpu_ctx *c);
+int tc_launch_commit_rhom(tcgpu_ctx *c);
 int tc_launch_density(tcgpu_ctx *c);
+int tc_launch_iter(tcgpu_ctx *c, int with_wvt);   /* fused density (+ unit-step WVT sums) */
+int tc_launch_apply_step(tcgpu_ctx *c, double step);  /* delta = step * ustep, rhom <- rhom_next */
 int tc_launch_wvt(tcgpu_ctx *c, double step);
 int tc_launch_curl(tcgpu_ctx *c);
 int tc_launch_find_ngb(tcgpu_ctx *c, int ipart, float hsml);
