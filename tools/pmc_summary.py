@@ -16,7 +16,7 @@ def load(d):
 if __name__ == "__main__":
     for d in sys.argv[1:]:
         agg = load(d)
-        for k in ('k_density', 'k_wvt', 'k_cells', 'k_keys', 'k_permute'):
+        for k in ('k_iter', 'k_density', 'k_wvt', 'k_cells', 'k_keys', 'k_permute'):
             if k in agg:
                 print(d, k)
                 for c, v in sorted(agg[k].items()):
