@@ -185,6 +185,47 @@ __device__ __forceinline__ bool is_orphan(const tc_dev_const &k, float4 p)
     return (double)p.x >= k.boxsize || (double)p.y >= k.boxsize || (double)p.z >= k.boxsize;
 }
 
+/* tc_ngb_r2 / tc_pair_r with the minimum-image folding under a wave-uniform flag: when every
+ * candidate of a particle provably lies within box/2 per coordinate (no wrapped cell is visited),
+ * none of the reference's `> boxhalf` tests can fire and the folding is skipped. */
+__device__ __forceinline__ float ngb_r2_w(float xi, float yi, float zi, float xj, float yj, float zj, float boxhalf,
+                                          float boxsize, bool wrap)
+{
+    float dx = fabsf(xi - xj), dy = fabsf(yi - yj), dz = fabsf(zi - zj);
+    if (wrap) {
+        if (dx > boxhalf) dx -= boxsize;
+        if (dy > boxhalf) dy -= boxsize;
+        if (dz > boxhalf) dz -= boxsize;
+    }
+    return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ double pair_r_w(float xi, float yi, float zi, float xj, float yj, float zj, double boxhalf,
+                                           double boxsize, bool wrap)
+{
+    double dx = (double)xi - (double)xj, dy = (double)yi - (double)yj, dz = (double)zi - (double)zj;
+    if (wrap) {
+        if (dx > boxhalf) dx -= boxsize;
+        if (dx < -boxhalf) dx += boxsize;
+        if (dy > boxhalf) dy -= boxsize;
+        if (dy < -boxhalf) dy += boxsize;
+        if (dz > boxhalf) dz -= boxsize;
+        if (dz < -boxhalf) dz += boxsize;
+    }
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+/* cell edge the query of radius h will use (same level rule as query_setup) */
+__device__ __forceinline__ double query_cell_edge(const tc_dev_const &k, float h)
+{
+    double ratio = k.boxsize / (double)h;
+    int L = (ratio >= 1.0) ? (ilogb(ratio) + 1) : 1;
+    L += k.level_shift;
+    if (L < 1) L = 1;
+    if (L > k.lmax) L = k.lmax;
+    return k.boxsize / (double)(1 << L);
+}
+
 /* Consumer: walk the flat index list, four independent gathers in flight per lane. */
 template <class Body>
 __device__ __forceinline__ bool consume_candidates(const tc_dev_const &k, const uint32_t *idx, int fill, int norph,
@@ -670,17 +711,19 @@ struct tc_wvt_args {
 
 /* accumulate one neighbour's contribution, src/wvt_relax.c:144-169 */
 __device__ __forceinline__ void wvt_pair(const float4 pi, const float4 pj, double boxinv, double step_hi,
-                                         double &d0, double &d1, double &d2)
+                                         double &d0, double &d1, double &d2, bool wrap = true)
 {
     float dx = (float)((double)(pi.x - pj.x) * boxinv);
     float dy = (float)((double)(pi.y - pj.y) * boxinv);
     float dz = (float)((double)(pi.z - pj.z) * boxinv);
-    dx = (double)dx > 0.5 ? (float)((double)dx - 1) : dx;
-    dy = (double)dy > 0.5 ? (float)((double)dy - 1) : dy;
-    dz = (double)dz > 0.5 ? (float)((double)dz - 1) : dz;
-    dx = (double)dx < -0.5 ? (float)((double)dx + 1) : dx;
-    dy = (double)dy < -0.5 ? (float)((double)dy + 1) : dy;
-    dz = (double)dz < -0.5 ? (float)((double)dz + 1) : dz;
+    if (wrap) {          /* wave-uniform: false when the particle's whole candidate region is inside the box */
+        dx = (double)dx > 0.5 ? (float)((double)dx - 1) : dx;
+        dy = (double)dy > 0.5 ? (float)((double)dy - 1) : dy;
+        dz = (double)dz > 0.5 ? (float)((double)dz - 1) : dz;
+        dx = (double)dx < -0.5 ? (float)((double)dx + 1) : dx;
+        dy = (double)dy < -0.5 ? (float)((double)dy + 1) : dy;
+        dz = (double)dz < -0.5 ? (float)((double)dz + 1) : dz;
+    }
     float r2 = (dx * dx + dy * dy + dz * dz);
     float h = (float)(0.5 * (double)(pi.w + pj.w));
     if (r2 > h * h) return;
@@ -864,6 +907,11 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         const float Rsq = R * R;
         const double boxinv = 1 / k.boxsize;
         const double step_hi = (double)pi.w;                          /* unit step */
+        /* every candidate lies in a cell overlapping [x-R', x+R'], i.e. within R' + s of x per coordinate */
+        const double ext = (double)R * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge(k, R);
+        const bool wrap = U((int)!((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
+                                   && (double)yi <= k.boxsize - ext && (double)zi >= ext
+                                   && (double)zi <= k.boxsize - ext)) != 0;
 
         tc_list2 L;
         L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
@@ -880,7 +928,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             const bool inn = dens && (r2 < h0sq);
             const bool outr = dens && !inn;
             double r = 0;
-            if (dens) r = tc_pair_r(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize);
+            if (dens) r = pair_r_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize, wrap);
             const uint64_t m_in = __ballot(inn), m_out = __ballot(outr);
             if (inn) { int slot = cs + mask_rank(m_in); if (slot < TC_NGBMAX) L.in.put(slot, r); }
             if (outr) { int slot = co + mask_rank(m_out); if (slot < TC_NGBMAX) L.out.put(slot, r); }
@@ -889,13 +937,13 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             if (do_wvt) {
                 const bool wv = valid && (r2 < hwsq);
                 cw = U(cw + (int)__popcll(__ballot(wv)));
-                if (wv && !signbit(r2)) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2);
+                if (wv && !signbit(r2)) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wrap);
             }
             head = U((head + 64) & (TC_STAGE - 1));
             wave_lds_fence();
         };
         d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
-            float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+            float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wrap);
             bool hit = act && (r2 < Rsq);
             uint64_t m = __ballot(hit);
             if (hit) {
