@@ -255,6 +255,53 @@ def test_relaxation_to_convergence_matches_oracle(gpu):
     assert rel(p["hsml"], q["hsml"]).max() < TOL_HSML and rel(p["rho"], q["rho"]).max() < TOL_RHO
 
 
+def test_config1_full_relaxation(gpu):
+    """BASELINE config 1: stock cluster.par shape, Ntotal 200000 -> 1e5 gas particles, single cluster,
+    relaxed until the reference's stop rule fires; compared with the oracle run on the host cores."""
+    n = 100_000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=14041981)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    log = gpu.Regularise_sph_particles()
+    gpu.Find_sph_quantities()                                  # main.c:54
+    o = O.Oracle(m, pos, ids)
+    olog = o.regularise()
+    o.find_sph_quantities()
+    assert len(log) == len(olog)
+    for a, b in zip(log, olog):
+        assert a["it"] == b["it"] and a["step"] == b["step"]
+        assert a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-5)
+        assert a["err_max"] == pytest.approx(b["err_max"], rel=1e-4)
+        assert binding.format_log_line(a)[:17] == O.format_log_line(b)[:17]      # '   #NN: Err max=N'
+    p, q = gpu.particles(), o.particles()
+    assert np.array_equal(p["id"], q["id"])
+    dpos = np.abs(p["pos"] - q["pos"]).max(axis=1) / q["hsml"]
+    assert dpos.max() < TOL_POS and dpos.mean() < 1e-5
+    assert rel(p["hsml"], q["hsml"]).max() < TOL_HSML and rel(p["rho"], q["rho"]).max() < TOL_RHO
+
+
+def test_many_halos_substructure_shape(gpu):
+    """BASELINE config 4 shape: two clusters + a population of small gas halos (Nhalos = 14); stresses the
+    density model loop and the density contrast handled by the cell hierarchy."""
+    n = 40_000
+    m = M.with_subhalos(M.preset("merger", n), 12, n)
+    pos, ids = M.sample_gas(m, n, seed=31)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    log = gpu.Regularise_sph_particles(max_iter=5)
+    o = O.Oracle(m, pos, ids)
+    olog = o.regularise(max_iter=5)
+    assert len(log) == len(olog) == 6
+    for a, b in zip(log, olog):
+        assert a["step"] == b["step"] and a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-5)
+        assert a["err_max"] == pytest.approx(b["err_max"], rel=1e-3)
+    p, q = gpu.particles(), o.particles()
+    assert np.array_equal(p["id"], q["id"])
+    assert (np.abs(p["pos"] - q["pos"]).max(axis=1) / q["hsml"]).max() < TOL_POS
+    assert rel(p["rho_model"], q["rho_model"]).max() < 1e-4      # evaluated at positions that agree to T2
+
+
 # ------------------------------------------------------------------ T2: curl
 
 def test_curl_of_vector_potential(gpu, golden_case):
@@ -335,6 +382,28 @@ def test_sharded_path_with_loopback_ranks(nranks):
             assert a["err_max"] == b["err_max"]
         for k in ("id", "pos", "hsml", "rho", "varhsmlfac"):
             assert np.array_equal(p[k], p1[k]), (r, k)
+
+
+def test_curl_larger_case_vs_oracle(gpu):
+    """BASELINE config 5 shape (curl of the Bonafede vector potential) at a size the oracle does in seconds."""
+    n = 60_000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=41)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    gpu.Find_sph_quantities()
+    p = gpu.particles()
+    rm = gpu.Global_density_model()
+    a = (rm / np.float32(m.halos[0].rho0)) ** np.float32(0.5)          # magnetic_field.c:57, eta = 0.5
+    apot = np.stack([a, a, a], axis=1).astype(np.float32)
+    b = gpu.Bfld_from_rotA_SPH(apot)
+    o = O.Oracle(m, pos, ids)
+    o.find_sph_quantities()
+    q = o.particles()
+    assert np.array_equal(p["id"], q["id"])
+    o.set_apot(apot)
+    bo = o.bfld_from_rotA()
+    assert np.abs(b - bo).max() < 1e-5 * np.abs(bo).max()
 
 
 # ------------------------------------------------------------------ error behaviour

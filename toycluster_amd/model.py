@@ -83,6 +83,29 @@ def preset(name, npart):
     return m
 
 
+def with_subhalos(model: ClusterModel, nsub, npart, seed=4):
+    """A BASELINE-config-4-shaped model: the preset plus `nsub` small gas halos inside the main cluster
+    (stand-in for the Giocoli substructure population of src/substructure.c, which is out of scope: the hot
+    path only sees more entries in Halo[] and a clumpier density field)."""
+    rng = np.random.default_rng(seed)
+    h0 = model.halos[0]
+    halos = list(model.halos)
+    for _ in range(nsub):
+        r = 1500.0 * rng.random() ** (1 / 3)
+        cth, phi = 2 * rng.random() - 1, 2 * np.pi * rng.random()
+        sth = np.sqrt(1 - cth * cth)
+        d = (h0.d_com[0] + r * sth * np.cos(phi), h0.d_com[1] + r * sth * np.sin(phi), h0.d_com[2] + r * cth)
+        rc = 20.0 + 40.0 * rng.random()
+        halos.append(Halo(rho0=h0.rho0 * (2 + 6 * rng.random()), beta=h0.beta, rcore=rc, rcut=6 * rc, d_com=d,
+                          r_sample=10 * rc))
+    m = ClusterModel(boxsize=model.boxsize, halos=halos, mtotal=model.mtotal, name=model.name + "+sub%d" % nsub)
+    for h in m.halos:
+        r, mt = _mass_table(h, h.r_sample)
+        h.mass_gas = float(mt[-1])
+    m.mpart_gas = sum(h.mass_gas for h in m.halos) / npart
+    return m
+
+
 def make_ids(n):
     """ids.c:16-39: gas ids strided by the smallest divisor >= 128 of n."""
     delta = 127
