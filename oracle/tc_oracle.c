@@ -526,6 +526,9 @@ static inline float dwc6(const float r, const float h)
            * (16 * u * u + 7 * u + 1);
 }
 
+float orc_wc6(float r, float h) { return wc6(r, h); }
+float orc_dwc6(float r, float h) { return dwc6(r, h); }
+
 /* sph.c:80-214 */
 static bool find_hsml(const orc_state *s, int ipart, const int32_t *ngblist, int ngbcnt,
                       float *dRhodHsml_out, float *hsml_out, float *rho_out,
@@ -693,6 +696,8 @@ static inline double wvt_wc6(const float r, const float h)
     const double t = 1 - u;
     return 1365.0 / (64 * ORC_PI) * t * t * t * t * t * t * t * t * (1 + 8 * u + 25 * u * u + 32 * u * u * u);
 }
+
+double orc_wvt_wc6(float r, float h) { return wvt_wc6(r, h); }
 
 /* wvt_relax.c:106-214 */
 void orc_wvt_step(orc_state *s, double step, float *hsml_out, float *delta_out, int move)

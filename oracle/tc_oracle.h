@@ -94,6 +94,11 @@ void orc_wvt_step(orc_state *s, double step, float *hsml_wvt, float *delta3, int
 /* sph.c:216-300 */
 void orc_bfld_from_rotA(orc_state *s);
 
+/* sph.c:426-440, wvt_relax.c:275-281 (scalar kernels, for unit checks) */
+float orc_wc6(float r, float h);
+float orc_dwc6(float r, float h);
+double orc_wvt_wc6(float r, float h);
+
 /* stats of the last orc_find_sph_quantities call */
 void orc_last_stats(const orc_state *s, double *queries_per_part, double *solver_iters_per_part,
                     double *pair_evals_per_part);
