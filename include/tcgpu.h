@@ -131,6 +131,9 @@ int tcgpu_wvt_step(tcgpu_ctx *ctx, double step, float *hsml_wvt, float *delta, i
 /* First half of one loop body (src/wvt_relax.c:66-87): Find_sph_quantities() + the error sums.
  * One WVT "step" of the benchmark = tcgpu_density_error() + tcgpu_wvt_step(move=1). */
 int tcgpu_density_error(tcgpu_ctx *ctx, double *err_mean, double *err_max);
+/* Sharded contexts: after tcgpu_density_error() only hsml is exchanged between the ranks; rho and
+ * varHsmlFac are complete on every rank after tcgpu_find_sph_quantities() or
+ * tcgpu_regularise_sph_particles(). */
 /* src/wvt_relax.c:25-225.  max_iter < 0 => NUMITER.  log has TCGPU_MAXLOG slots. */
 int tcgpu_regularise_sph_particles(tcgpu_ctx *ctx, int max_iter, tcgpu_iterlog *log, int32_t *nlog);
 /* src/sph.c:216-300.  apot: f32[3n] in the CURRENT order; bfld out f32[3n]. */

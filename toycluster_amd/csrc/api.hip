@@ -178,12 +178,13 @@ extern "C" int tcgpu_set_model(tcgpu_ctx *c, const tcgpu_params *par, const tcgp
 
 static int pick_lmax(int64_t n)
 {
-    /* deepest level ~ two levels below the mean inter-particle level: ceil(log8 n) + 2 */
-    int l = 0;
-    int64_t c = 1;
-    while (c < n) { c *= 8; l++; }
-    l += 2;
+    /* Deepest table level: about two levels below the mean inter-particle level, round(log8 n) + 2.
+     * The whole table is cleared every iteration (8^L x 8 B: 1.2 GB at L = 9, 9.8 GB at L = 10), so
+     * L = 10 is only used where the densest particles need it (n >= 3e7); a clamped level just means
+     * more candidates per query for the few particles with hsml below the deepest cell size. */
+    int l = (int)floor(log((double)(n > 1 ? n : 1)) / log(8.0) + 0.5) + 2;
     if (l < 3) l = 3;
+    if (l > 9 && n < 30000000) l = 9;
     if (l > TC_MAX_LEVEL) l = TC_MAX_LEVEL;
     return l;
 }
@@ -540,7 +541,24 @@ static int density_stats(tcgpu_ctx *c)
     return 0;
 }
 
-static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess, int with_wvt)
+/* gather_all: also all-gather rho and varHsmlFac (needed once results are read back; inside the
+ * relaxation loop other ranks only need the carried hsml for their next warm start) */
+static int gather_sph(tcgpu_ctx *c, int gather_all)
+{
+    if (!(c->comm || c->loop)) return 0;
+    tc_phase_begin(c, PH_COMM);
+    if (c->comm) g_rccl.GroupStart();
+    int r1 = allgather_inplace(c, c->hsml[c->cur], sizeof(float)), r2 = 0, r3 = 0;
+    if (gather_all) {
+        r2 = allgather_inplace(c, c->rho[c->cur], sizeof(float));
+        r3 = allgather_inplace(c, c->vhf[c->cur], sizeof(float));
+    }
+    if (c->comm) g_rccl.GroupEnd();
+    tc_phase_end(c);
+    return (r1 || r2 || r3) ? TCGPU_ERR_COMM : 0;
+}
+
+static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess, int with_wvt, int gather_all)
 {
     int rc;
     if ((rc = tcgpu_sort_particles_by_peano_key(c))) return rc;
@@ -553,24 +571,14 @@ static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess, int with_wv
         if ((rc = tc_launch_iter(c, with_wvt))) return rc;
         c->ustep_valid = with_wvt;
     } else if ((rc = tc_launch_density(c))) return rc;
-    if (c->comm || c->loop) {
-        tc_phase_begin(c, PH_COMM);
-        if (c->comm) g_rccl.GroupStart();
-        int r1 = allgather_inplace(c, c->hsml[c->cur], sizeof(float));
-        int r2 = allgather_inplace(c, c->rho[c->cur], sizeof(float));
-        int r3 = allgather_inplace(c, c->vhf[c->cur], sizeof(float));
-        if (c->comm) g_rccl.GroupEnd();
-        tc_phase_end(c);
-        if (r1 || r2 || r3) return TCGPU_ERR_COMM;
-    }
-    return 0;
+    return gather_sph(c, gather_all);
 }
 
 extern "C" int tcgpu_find_sph_quantities(tcgpu_ctx *c)
 {
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
-    int rc = find_sph_quantities_nocheck(c, c->need_guess, 0);
+    int rc = find_sph_quantities_nocheck(c, c->need_guess, 0, 1);
     if (rc) return rc;
     rc = check_flags(c);
     if (rc) return rc;
@@ -678,7 +686,7 @@ extern "C" int tcgpu_wvt_step(tcgpu_ctx *c, double step, float *hsml_wvt, float 
 static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, double *err_max)
 {
     int rc;
-    if ((rc = find_sph_quantities_nocheck(c, need_guess, 1))) return rc;
+    if ((rc = find_sph_quantities_nocheck(c, need_guess, 1, 0))) return rc;
     if ((rc = tc_launch_error(c))) return rc;
     double *fin = c->red + 4 * TC_RED_BLOCKS;
     if (c->comm || c->loop) {
@@ -738,6 +746,7 @@ extern "C" int tcgpu_regularise_sph_particles(tcgpu_ctx *c, int max_iter, tcgpu_
 
         if ((rc = wvt_step_nocheck(c, step, 1))) return rc;
     }
+    if ((rc = gather_sph(c, 1))) return rc;                   /* rho / varHsmlFac of the last pass, all ranks */
     TC_HIP(c, hipStreamSynchronize(c->stream));
     tc_phase_collect(c);
     if (nlog_out) *nlog_out = nlog;
