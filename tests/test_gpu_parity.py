@@ -89,6 +89,38 @@ def test_sort_with_duplicates_and_box_faces(gpu):
             assert np.array_equal(a, b), (i, h, len(a), len(b))
 
 
+def test_sort_keys_tying_in_the_high_half(gpu):
+    """Particles a few f32 ulps apart share the high 64 key bits (21 Hilbert levels) and differ only in the
+    low half: the one-pass radix sort + tie fix-up must still give the full 128-bit order.  Includes a run
+    of 40 such particles (heapsort branch of the fix-up) and exact duplicates."""
+    n = 6000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=77)
+    base = pos[1000].copy()
+    base[:] = np.float32(m.boxsize) * np.float32([0.731, 0.642, 0.553])
+    for k in range(40):                                  # consecutive floats in x, scrambled order
+        pos[2000 + (k * 7) % 40] = base
+        pos[2000 + (k * 7) % 40, 0] = np.nextafter(base[0], np.float32(np.inf), dtype=np.float32) if k == 0 else \
+            np.float32(base[0]) + np.float32(k) * np.spacing(np.float32(base[0]))
+    pos[3000] = pos[3001] = pos[3002]                    # exact triple
+    pos[3100, :] = pos[3101, :]
+    pos[3101, 2] = np.nextafter(pos[3100, 2], np.float32(0), dtype=np.float32)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    hi, lo = gpu.Sort_Particles_By_Peano_Key()
+    o = O.Oracle(m, pos, ids)
+    ohi, olo, operm = o.sort_by_peano_key()
+    assert np.array_equal(hi, ohi) and np.array_equal(lo, olo)
+    assert (np.diff(hi.astype(np.float64)) == 0).sum() >= 40          # the case really has high-half ties
+    p, q = gpu.particles(), o.particles()
+    k = (hi.astype(object) << 64) | lo.astype(object)
+    distinct = np.r_[True, k[1:] != k[:-1]] & np.r_[k[1:] != k[:-1], True]
+    assert np.array_equal(p["id"][distinct], q["id"][distinct])       # unique keys: unique order
+    # identical keys keep their upload order (stable sort)
+    trip = np.flatnonzero(np.isin(p["id"], ids[3000:3003]))
+    assert list(p["id"][trip]) == list(ids[3000:3003])
+
+
 # ------------------------------------------------------------------ T1: neighbour sets
 
 def test_neighbour_sets_exact(gpu, golden_case):

@@ -564,7 +564,7 @@ static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess, int with_wv
     if ((rc = tcgpu_sort_particles_by_peano_key(c))) return rc;
     if ((rc = tc_launch_cells(c))) return rc;
     if (need_guess && (rc = tc_launch_guess(c))) return rc;
-    if (c->fuse && !c->ablate) {
+    if (c->fuse) {
         /* one gather per particle serves the density solve and (with_wvt) the WVT sweep that
          * follows on the same positions; the sweep needs the model hsml up front */
         if (with_wvt && (rc = tc_launch_model_hsml(c))) return rc;

@@ -164,7 +164,7 @@ __device__ __forceinline__ void query_cell(const tc_dev_const &k, const tc_query
     const int off[3] = {a, b, cc};
     const float xs[3] = {xi, yi, zi};
     float g2 = 0;
-    size_t lin = 0;
+    uint32_t lin = 0;                             /* 3L <= 30 bits */
     for (int d = 0; d < 3; d++) {
         int u = q.lo[d] + off[d];                 /* unwrapped cell coordinate */
         if (!q.full[d]) {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void query_cell(const tc_dev_const &k, const tc_query
             float g = xs[d] < clo ? clo - xs[d] : (xs[d] > chi ? xs[d] - chi : 0.0f);
             g2 += g * g;
         }
-        lin = lin * (size_t)q.nL + (size_t)(u & (q.nL - 1));
+        lin = (lin << q.L) | (uint32_t)(u & (q.nL - 1));
     }
     if (g2 > q.hpf * q.hpf) return;
     uint2 ce = k.cells[q.off + lin];            /* {~first, last+1}, both 0 when empty */
@@ -870,7 +870,7 @@ struct tc_iter_args {
 #define TC_ICAP 512            /* inner entries in LDS */
 #define TC_OCAP 384            /* outer entries in LDS */
 #define TC_ITER_IDXCAP 512
-#define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 5 * TC_STAGE * sizeof(float))
+#define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 8 * TC_STAGE * sizeof(float))
 
 __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
 {
@@ -883,10 +883,12 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
 
     double *lds_lists = reinterpret_cast<double *>(mine);
     uint32_t *idx = reinterpret_cast<uint32_t *>(lds_lists + TC_ICAP + TC_OCAP);
-    tc_stage st;
+    /* two staging rings: density hits (x, y, z, r2) and sweep hits (x, y, z, hsml_wvt) */
+    tc_stage st;                                      /* density ring; st.w holds r2 here */
     st.x = reinterpret_cast<float *>(idx + TC_ITER_IDXCAP);
     st.y = st.x + TC_STAGE; st.z = st.y + TC_STAGE; st.w = st.z + TC_STAGE;
-    float *st_r2 = st.w + TC_STAGE;
+    tc_stage sw;                                      /* sweep ring */
+    sw.x = st.w + TC_STAGE; sw.y = sw.x + TC_STAGE; sw.z = sw.y + TC_STAGE; sw.w = sw.z + TC_STAGE;
     const uint32_t idxcap = TC_ITER_IDXCAP;
     tc_rlist plain;                                   /* the fallback path sees one list over both LDS parts */
     plain.lds = lds_lists; plain.spill = spill; plain.cap = TC_ICAP + TC_OCAP;
@@ -904,7 +906,6 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         const float hw = (float)((double)pi.w * k.boxsize);          /* src/wvt_relax.c:135 */
         const float hwsq = hw * hw;
         const float R = (do_wvt && hw > hb) ? hw : hb;
-        const float Rsq = R * R;
         const double boxinv = 1 / k.boxsize;
         const double step_hi = (double)pi.w;                          /* unit step */
         /* every candidate lies in a cell overlapping [x-R', x+R'], i.e. within R' + s of x per coordinate */
@@ -916,57 +917,79 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         tc_list2 L;
         L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
         L.out.lds = lds_lists + TC_ICAP; L.out.spill = spill + TC_NGBMAX;  L.out.cap = TC_OCAP;
-        int cs = 0, co = 0, cw = 0, scnt = 0, head = 0;
+        int cs = 0, co = 0, cw = 0;
+        int dcnt = 0, dhead = 0, wcnt = 0, whead = 0;
 
-        auto convert = [&](int nvalid) {
+        /* 64 staged density hits -> f64 separations -> inner / outer list */
+        auto convert_d = [&](int nvalid) {
             wave_lds_fence();
-            int sl = (head + lane) & (TC_STAGE - 1);
-            float4 p = make_float4(st.x[sl], st.y[sl], st.z[sl], st.w[sl]);
-            float r2 = st_r2[sl];                                      /* sign bit set <=> the particle itself */
+            int sl = (dhead + lane) & (TC_STAGE - 1);
+            float x = st.x[sl], y = st.y[sl], z = st.z[sl], r2 = st.w[sl];
             const bool valid = lane < nvalid;
-            const bool dens = valid && (r2 < hbsq);
-            const bool inn = dens && (r2 < h0sq);
-            const bool outr = dens && !inn;
+            const bool inn = valid && (r2 < h0sq);
+            const bool outr = valid && !inn;
             double r = 0;
-            if (dens) r = pair_r_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf, k.boxsize, wrap);
+            if (valid && k.ablate != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wrap);
             const uint64_t m_in = __ballot(inn), m_out = __ballot(outr);
             if (inn) { int slot = cs + mask_rank(m_in); if (slot < TC_NGBMAX) L.in.put(slot, r); }
             if (outr) { int slot = co + mask_rank(m_out); if (slot < TC_NGBMAX) L.out.put(slot, r); }
             cs = U(cs + (int)__popcll(m_in));
             co = U(co + (int)__popcll(m_out));
-            if (do_wvt) {
-                const bool wv = valid && (r2 < hwsq);
-                cw = U(cw + (int)__popcll(__ballot(wv)));
-                if (wv && !signbit(r2)) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wrap);
-            }
-            head = U((head + 64) & (TC_STAGE - 1));
+            dhead = U((dhead + 64) & (TC_STAGE - 1));
+            wave_lds_fence();
+        };
+        /* 64 staged sweep hits -> pair terms */
+        auto convert_w = [&](int nvalid) {
+            wave_lds_fence();
+            int sl = (whead + lane) & (TC_STAGE - 1);
+            float4 p = make_float4(sw.x[sl], sw.y[sl], sw.z[sl], sw.w[sl]);
+            if (lane < nvalid && k.ablate != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wrap);
+            whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
         };
         d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
             float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wrap);
-            bool hit = act && (r2 < Rsq);
-            uint64_t m = __ballot(hit);
-            if (hit) {
-                int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
-                st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = p.w;
-                st_r2[sl] = (j == i) ? -r2 : r2;                       /* r2 == 0 for the particle itself: -0.0f */
+            const bool hd = act && (r2 < hbsq);
+            const uint64_t md = __ballot(hd);
+            if (k.ablate == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
+            if (hd) {
+                int sl = (dhead + dcnt + mask_rank(md)) & (TC_STAGE - 1);
+                st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = r2;
             }
-            scnt = U(scnt + (int)__popcll(m));
-            if (scnt >= 64) { convert(64); scnt = U(scnt - 64); }
-            return cs + co >= TC_NGBMAX;
+            dcnt = U(dcnt + (int)__popcll(md));
+            if (dcnt >= 64) { convert_d(64); dcnt = U(dcnt - 64); }
+            if (do_wvt) {
+                const bool hwv = act && (r2 < hwsq);
+                cw = U(cw + (int)__popcll(__ballot(hwv)));
+                const bool use = hwv && j != i;
+                const uint64_t mw = __ballot(use);
+                if (use) {
+                    int sl = (whead + wcnt + mask_rank(mw)) & (TC_STAGE - 1);
+                    sw.x[sl] = p.x; sw.y[sl] = p.y; sw.z[sl] = p.z; sw.w[sl] = p.w;
+                }
+                wcnt = U(wcnt + (int)__popcll(mw));
+                if (wcnt >= 64) { convert_w(64); wcnt = U(wcnt - 64); }
+            }
+            return cs + co + dcnt >= TC_NGBMAX;
         });
-        if (cs + co < TC_NGBMAX && scnt > 0) convert(scnt);
+        const bool overflow = cs + co + dcnt >= TC_NGBMAX;
+        if (!overflow) {
+            if (dcnt > 0) convert_d(dcnt);
+            if (do_wvt && wcnt > 0) convert_w(wcnt);
+        }
         wave_lds_fence();
         const int ca = cs + co;
 
-        if (ca < TC_NGBMAX) {
+        if (!overflow) {
             if (do_wvt && cw < TC_NGBMAX) {
                 u0 = wsum(u0); u1 = wsum(u1); u2 = wsum(u2);
                 wvt_done = true;
             }
             /* src/sph.c:36-64 on the two virtual queries */
             bool solved = false;
-            if (cs >= TC_DESNNGB) {                                    /* first query already has >= 295 */
+            if (k.ablate) {                                            /* profiling only: no solve */
+                solved = true; d.rho = 1; wvt_done = true;
+            } else if (cs >= TC_DESNNGB) {                                    /* first query already has >= 295 */
                 d.nq += 1;
                 L.cs = cs;
                 solved = solve_hsml(L, cs, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair);
@@ -982,7 +1005,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             }
             if (solved) d.ok = true;
         }
-        /* ca >= NGBMAX: the first or second query of the reference would have overflowed its list;
+        /* overflow: the first or second query of the reference would have filled its NGBMAX list;
          * replay it exactly from the carried hsml with the plain code */
     }
 
@@ -990,7 +1013,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     if (finite) density_store(da, i, d);
 
     if (do_wvt) {
-        if (!wvt_done) wvt_sum(k, i, pi, (double)pi.w, da.flags, idx, TC_ITER_IDXCAP, st, u0, u1, u2);
+        if (!wvt_done) wvt_sum(k, i, pi, (double)pi.w, da.flags, idx, TC_ITER_IDXCAP, sw, u0, u1, u2);
         if (lane == 0) {
             a.ustep[3 * (size_t)i] = u0;
             a.ustep[3 * (size_t)i + 1] = u1;
