@@ -201,6 +201,28 @@ def test_density_pass_cold(gpu, golden_case):
     assert (p["rho"] == c["d_rho"]).mean() > 0.99
 
 
+def test_density_pass_tiny_input(gpu):
+    """Barely more particles than DESNNGB: smoothing lengths comparable to the box (whole-box queries,
+    periodic images), many x1.23 retries.  The reference would hang below 256 particles per thread
+    (SURVEY.md section 5); the library has no such limit."""
+    n = 700
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=13)
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    gpu.Find_sph_quantities()
+    p = gpu.particles()
+    o = O.Oracle(m, pos, ids, nthreads=1)
+    o.find_sph_quantities()
+    q = o.particles()
+    assert np.array_equal(p["id"], q["id"])
+    assert rel(p["hsml"], q["hsml"]).max() < 1e-6 and rel(p["rho"], q["rho"]).max() < 1e-6
+    assert p["hsml"].max() > 0.3 * m.boxsize
+    log = gpu.Regularise_sph_particles(max_iter=2)
+    olog = o.regularise(max_iter=2)
+    assert [l["err_mean"] for l in log] == pytest.approx([l["err_mean"] for l in olog], rel=1e-5)
+
+
 def test_density_pass_warm_and_idempotent(gpu):
     n = 30000
     m = M.preset("merger", n)
