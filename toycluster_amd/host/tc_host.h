@@ -76,6 +76,33 @@ typedef struct {
 /* 0 on success, 5/6 on I/O error (the reference's exit codes, src/io.c:256,280) */
 int tc_write_snapshot(const char *filename, const tc_snapshot *s);
 
+/* ---- stages in front of the hot path: units, cosmology, halo set-up, sampling ---- */
+typedef struct {                      /* the fields of the reference's HaloProperties that Setup() fills */
+    double mtotal200, mass200[2];     /* [0] gas, [1] dark matter */
+    double c_nfw, r200, rs, a_hernq;
+    double rho0, beta, rcore, rcut;
+    double r_sample[2], mass[2], mtotal, mass_corr_fac;
+    double d_com[3];
+    long long npart[2];
+    int have_cuspy, pad_;
+} tc_halo_setup;
+
+typedef struct {
+    tc_parfile par;
+    double unit_length, unit_mass, unit_vel, unit_time;
+    double h_100, omega_m, omega_l, h0_cgs, rho_crit, delta;   /* rho_crit at the cluster redshift, Delta_vir */
+    int nhalos, pad_;
+    tc_halo_setup halo[2];
+    double boxsize, mtotal, mpart[2];
+    long long npart[2];
+} tc_setup;
+
+/* Set_units + Set_cosmology + Setup (src/unit.c, src/cosmo.c, src/setup.c:21-344), default build options */
+int  tc_setup_system(const tc_parfile *par, tc_setup *out);
+void tc_setup_to_model(const tc_setup *s, tcgpu_params *par, tcgpu_halo *halos /* [2] */);
+/* Make_positions (gas), Make_IDs, Shift_Origin: pos f32[3*npart[0]] in [0,boxsize], id i32[npart[0]] */
+int  tc_sample_gas(const tc_setup *s, int nthreads, float *pos, int32_t *id);
+
 /* ---- state file ---- */
 typedef struct {
     tcgpu_params par;

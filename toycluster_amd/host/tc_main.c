@@ -1,7 +1,11 @@
 /*
  * toycluster_hip -- C host program for the MI355X SPH/WVT path.
  *
- *   usage: ./toycluster_hip <parameterfile> <statefile> [device]
+ *   usage: ./toycluster_hip <parameterfile> [statefile|-] [device]
+ *
+ * Without a state file the set-up stages run natively (tc_setup.c: units, cosmology, halo scalars,
+ * gas sampling, ids, origin shift -- the gas half of src/main.c:32-46); with one, their result is
+ * read from it (e.g. a state dumped from a real Toycluster run).
  *
  * It is the gas branch of the reference's main() (src/main.c:50-69) with the hot path running on
  * the GPU through libtcgpu's C ABI:
@@ -37,8 +41,8 @@ static double gas_density_profile(double r, const tcgpu_halo *h)
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) {
-        fprintf(stderr, "usage : ./toycluster_hip $parameterfile $statefile [device]\n");
+    if (argc < 2) {
+        fprintf(stderr, "usage : ./toycluster_hip $parameterfile [$statefile|-] [device]\n");
         return EXIT_FAILURE;
     }
     char err[1024];
@@ -47,7 +51,30 @@ int main(int argc, char **argv)
     printf("\nReading Parameter file : %s \n\n", argv[1]);
 
     tc_state st;
-    if (tc_read_state(argv[2], &st, err, sizeof(err))) die(EXIT_FAILURE, "state file", err);
+    if (argc > 2 && strcmp(argv[2], "-")) {
+        if (tc_read_state(argv[2], &st, err, sizeof(err))) die(EXIT_FAILURE, "state file", err);
+    } else {                                  /* Set_units .. Shift_Origin, natively */
+        tc_setup S;
+        tc_setup_system(&par, &S);
+        if (S.npart[0] <= 0) die(EXIT_FAILURE, "setup", "no gas particles (bf = 0): nothing for the SPH path to do");
+        printf("System Setup : \n   Boxsize         = %g kpc\n   Total Mass      = %g 10^10 Msol\n"
+               "   Sph Part Mass   = %g 10^10 Msol\n   Npart Total     = %8lld, %8lld\n\n",
+               S.boxsize, S.mtotal, S.mpart[0], S.npart[0], S.npart[1]);
+        for (int i = 0; i < S.nhalos; i++)
+            printf("Halo Setup : <%d>\n   R200 = %g kpc  c_nfw = %g  rho0_gas = %g [gadget]  beta = %g  rc = %g kpc  Rcut = %g kpc\n",
+                   i, S.halo[i].r200, S.halo[i].c_nfw, S.halo[i].rho0, S.halo[i].beta, S.halo[i].rcore, S.halo[i].rcut);
+        memset(&st, 0, sizeof(st));
+        st.ngas = S.npart[0];
+        st.halos = calloc(2, sizeof(tcgpu_halo));
+        st.pos = malloc(3 * (size_t)st.ngas * sizeof(float));
+        st.id = malloc((size_t)st.ngas * sizeof(int32_t));
+        if (!st.halos || !st.pos || !st.id) die(EXIT_FAILURE, "malloc", "out of memory");
+        tc_setup_to_model(&S, &st.par, st.halos);
+        const char *nt = getenv("OMP_NUM_THREADS");
+        printf("Sampling positions "); fflush(stdout);
+        tc_sample_gas(&S, nt ? atoi(nt) : 1, st.pos, st.id);
+        printf(" done\n");
+    }
     st.par.bfld_eta = par.bfld_eta;
     const size_t n = (size_t)st.ngas;
 

@@ -29,6 +29,61 @@ class Snapshot(C.Structure):
                 ("rho_model", C.c_void_p)]
 
 
+class HaloSetup(C.Structure):
+    _fields_ = [("mtotal200", C.c_double), ("mass200", C.c_double * 2), ("c_nfw", C.c_double), ("r200", C.c_double),
+                ("rs", C.c_double), ("a_hernq", C.c_double), ("rho0", C.c_double), ("beta", C.c_double),
+                ("rcore", C.c_double), ("rcut", C.c_double), ("r_sample", C.c_double * 2), ("mass", C.c_double * 2),
+                ("mtotal", C.c_double), ("mass_corr_fac", C.c_double), ("d_com", C.c_double * 3),
+                ("npart", C.c_longlong * 2), ("have_cuspy", C.c_int), ("pad_", C.c_int)]
+
+
+class Setup(C.Structure):
+    _fields_ = [("par", ParFile), ("unit_length", C.c_double), ("unit_mass", C.c_double), ("unit_vel", C.c_double),
+                ("unit_time", C.c_double), ("h_100", C.c_double), ("omega_m", C.c_double), ("omega_l", C.c_double),
+                ("h0_cgs", C.c_double), ("rho_crit", C.c_double), ("delta", C.c_double), ("nhalos", C.c_int),
+                ("pad_", C.c_int), ("halo", HaloSetup * 2), ("boxsize", C.c_double), ("mtotal", C.c_double),
+                ("mpart", C.c_double * 2), ("npart", C.c_longlong * 2)]
+
+
+def setup_system(parfile_path, overrides=None):
+    """Set_units + Set_cosmology + Setup of the reference, natively (host/tc_setup.c). `overrides` patches
+    parameter-file fields (e.g. {"ntotal": 200000, "mass_ratio": 0.3125}) before the set-up runs."""
+    L = _lib()
+    p = ParFile()
+    err = C.create_string_buffer(1024)
+    rc = L.tc_read_param_file(parfile_path.encode(), C.byref(p), err, 1024)
+    if rc:
+        raise RuntimeError(err.value.decode())
+    for k, v in (overrides or {}).items():
+        setattr(p, k, v)
+    s = Setup()
+    L.tc_setup_system.argtypes = [C.POINTER(ParFile), C.POINTER(Setup)]
+    L.tc_setup_system(C.byref(p), C.byref(s))
+    return s
+
+
+def sample_gas(setup, nthreads=1):
+    L = _lib()
+    n = int(setup.npart[0])
+    pos = np.empty((n, 3), np.float32)
+    ids = np.empty(n, np.int32)
+    L.tc_sample_gas.argtypes = [C.POINTER(Setup), C.c_int, C.c_void_p, C.c_void_p]
+    L.tc_sample_gas(C.byref(setup), int(nthreads), pos.ctypes.data, ids.ctypes.data)
+    return pos, ids
+
+
+def setup_to_model(setup):
+    """ClusterModel (the scalars the hot path reads) from a native set-up."""
+    from .model import ClusterModel, Halo
+    halos = []
+    for i in range(setup.nhalos):
+        h = setup.halo[i]
+        halos.append(Halo(rho0=h.rho0, beta=h.beta, rcore=h.rcore, rcut=h.rcut, d_com=tuple(h.d_com),
+                          r_sample=h.r_sample[0], mass_gas=h.mass[0], have_cuspy=h.have_cuspy))
+    return ClusterModel(boxsize=setup.boxsize, halos=halos, mpart_gas=setup.mpart[0], mtotal=setup.mtotal,
+                        bfld_eta=setup.par.bfld_eta, name="native-setup")
+
+
 def _lib():
     if not os.path.exists(HOSTLIB):
         raise RuntimeError("%s missing: run __graft_entry__.build()" % HOSTLIB)
