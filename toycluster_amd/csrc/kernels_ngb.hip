@@ -377,15 +377,34 @@ struct tc_density_args {
 };
 
 /* the hit list: r (f64) of every neighbour found by the last ball query */
+/* Visit list entries two at a time per lane (two independent f64 chains per trip); a missing
+ * second entry is replaced by `pad`.  One loop per storage segment so that every load has a single,
+ * known address space (a per-entry LDS-or-global select compiles to flat loads). */
+template <class F>
+__device__ __forceinline__ void scan_segment(const double *p, int n, double pad, F &&f)
+{
+    for (int kk = lane_id(); kk < n; kk += 128) {
+        const int k2 = kk + 64;
+        double ra = p[kk];
+        double rb = k2 < n ? p[k2] : pad;
+        f(ra, rb);
+    }
+}
+
 struct tc_rlist {
     double *lds;               /* `cap` entries */
     double *spill;             /* TC_NGBMAX entries (slot kk >= cap lives at spill[kk - cap]) */
     int cap;
-    __device__ __forceinline__ double get(int kk) const { return kk < cap ? lds[kk] : spill[kk - cap]; }
     __device__ __forceinline__ void put(int kk, double v) const
     {
         if (kk < cap) lds[kk] = v;
         else spill[kk - cap] = v;
+    }
+    template <class F>
+    __device__ __forceinline__ void scan(int cnt, double pad, F &&f) const
+    {
+        scan_segment(lds, cnt < cap ? cnt : cap, pad, f);
+        if (cnt > cap) scan_segment(spill, cnt - cap, pad, f);
     }
 };
 
@@ -393,8 +412,13 @@ struct tc_rlist {
  * out to 1.23 hsml ("outer"); as one list, inner entries come first */
 struct tc_list2 {
     tc_rlist in, out;
-    int cs;                    /* inner count: get(kk) switches lists there */
-    __device__ __forceinline__ double get(int kk) const { return kk < cs ? in.get(kk) : out.get(kk - cs); }
+    int cs;                    /* inner count */
+    template <class F>
+    __device__ __forceinline__ void scan(int cnt, double pad, F &&f) const
+    {
+        in.scan(cnt < cs ? cnt : cs, pad, f);
+        if (cnt > cs) out.scan(cnt - cs, pad, f);
+    }
 };
 
 /* ring of staged hit positions (and hsml_wvt for the sweep), TC_STAGE entries per wave */
@@ -415,7 +439,6 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
                                            float &hsml_io, float &rho_out, float &drho_io,
                                            uint32_t &iters, uint32_t &pairs)
 {
-    const int lane = lane_id();
     double upper = (double)hsml_io * TC_SQRT3;
     double lower = 0;
     double hsml = (double)hsml_io;
@@ -462,18 +485,15 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
             a2 = fma(nmpart, fma(three_h, wk, r * inv_h * dwk), a2);
         };
         /* two independent entries per lane and trip: the f64 chains are latency-bound otherwise.
-         * `r > hsml` entries are skipped: == (r2 > hsml^2) up to a zero-weight boundary */
+         * `r > hsml` entries are skipped: == (r2 > hsml^2) up to a zero-weight boundary;
+         * a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0 */
         double wkB = 0, rhoB = 0, dRhoB = 0;
-        for (int kk = lane; kk < cnt; kk += 128) {
-            const int k2 = kk + 64;
-            double ra = rl.get(kk);
-            double rb = k2 < cnt ? rl.get(k2) : hsml;
-            /* a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0 */
+        rl.scan(cnt, hsml, [&](double ra, double rb) {
             ra = ra > hsml ? hsml : ra;
             rb = rb > hsml ? hsml : rb;
             term(ra, wkNgb, rho, dRhodHsml);
             term(rb, wkB, rhoB, dRhoB);
-        }
+        });
         wkNgb += wkB; rho += rhoB; dRhodHsml += dRhoB;
         wkNgb = wsum(wkNgb);
         rho = wsum(rho);
