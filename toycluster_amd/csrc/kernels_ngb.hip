@@ -887,9 +887,12 @@ struct tc_iter_args {
     double *ustep;             /* 3n, unit-step displacement sums; NULL => density only */
 };
 
-#define TC_ICAP 512            /* inner entries in LDS */
-#define TC_OCAP 384            /* outer entries in LDS */
-#define TC_ITER_IDXCAP 512
+/* Sized for 4 waves per SIMD (<= 128 VGPRs, 4 blocks x 38.9 KB LDS per CU): measured 4 % faster than 3 waves
+ * with 512/384/512 (tools/try_libs.sh, same box).  Longer lists continue in the per-wave global spill. */
+#define TC_ICAP 384            /* inner entries in LDS */
+#define TC_OCAP 192            /* outer entries in LDS */
+#define TC_ITER_IDXCAP 256
+#define TC_ITER_MINWAVES 4
 #define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 8 * TC_STAGE * sizeof(float))
 
 __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
@@ -1042,7 +1045,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     }
 }
 
-__global__ __launch_bounds__(TBN) void k_iter(tc_iter_args a)
+__global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
 {
     __shared__ __align__(16) unsigned char lds_raw[WPB * TC_LDS_PER_WAVE_ITER];
     const int wave = threadIdx.x >> 6;
