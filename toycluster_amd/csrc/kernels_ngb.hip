@@ -889,11 +889,11 @@ struct tc_iter_args {
 
 /* Sized for 4 waves per SIMD (<= 128 VGPRs, 4 blocks x 38.9 KB LDS per CU): measured 4 % faster than 3 waves
  * with 512/384/512 (tools/try_libs.sh, same box).  Longer lists continue in the per-wave global spill. */
-#define TC_ICAP 384            /* inner entries in LDS */
-#define TC_OCAP 192            /* outer entries in LDS */
+#define TC_ICAP 512            /* inner entries in LDS */
+#define TC_OCAP 384            /* outer entries in LDS */
 #define TC_ITER_IDXCAP 256
 #define TC_ITER_MINWAVES 4
-#define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 8 * TC_STAGE * sizeof(float))
+#define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 4 * TC_STAGE * sizeof(float))
 
 __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
 {
@@ -906,12 +906,17 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
 
     double *lds_lists = reinterpret_cast<double *>(mine);
     uint32_t *idx = reinterpret_cast<uint32_t *>(lds_lists + TC_ICAP + TC_OCAP);
-    /* two staging rings: density hits (x, y, z, r2) and sweep hits (x, y, z, hsml_wvt) */
-    tc_stage st;                                      /* density ring; st.w holds r2 here */
-    st.x = reinterpret_cast<float *>(idx + TC_ITER_IDXCAP);
+    /* two staging rings of particle indices: density hits (j, r2) and sweep hits (j); positions are
+     * re-read at conversion time (they are L1/L2-hot), which keeps the rings small enough for the
+     * hit lists to stay in LDS at 4 waves per SIMD */
+    uint32_t *dj = idx + TC_ITER_IDXCAP;
+    float *dr2 = reinterpret_cast<float *>(dj + TC_STAGE);
+    uint32_t *wj = reinterpret_cast<uint32_t *>(dr2 + TC_STAGE);
+    /* the plain fallback code stages positions: it reuses the whole ring area (4 x TC_STAGE floats) */
+    tc_stage st;
+    st.x = reinterpret_cast<float *>(dj);
     st.y = st.x + TC_STAGE; st.z = st.y + TC_STAGE; st.w = st.z + TC_STAGE;
-    tc_stage sw;                                      /* sweep ring */
-    sw.x = st.w + TC_STAGE; sw.y = sw.x + TC_STAGE; sw.z = sw.y + TC_STAGE; sw.w = sw.z + TC_STAGE;
+    const tc_stage sw = st;
     const uint32_t idxcap = TC_ITER_IDXCAP;
     tc_rlist plain;                                   /* the fallback path sees one list over both LDS parts */
     plain.lds = lds_lists; plain.spill = spill; plain.cap = TC_ICAP + TC_OCAP;
@@ -947,8 +952,9 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         auto convert_d = [&](int nvalid) {
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
-            float x = st.x[sl], y = st.y[sl], z = st.z[sl], r2 = st.w[sl];
             const bool valid = lane < nvalid;
+            const float4 pj = k.pos4[valid ? dj[sl] : (uint32_t)i];
+            const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
             const bool inn = valid && (r2 < h0sq);
             const bool outr = valid && !inn;
             double r = 0;
@@ -965,7 +971,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         auto convert_w = [&](int nvalid) {
             wave_lds_fence();
             int sl = (whead + lane) & (TC_STAGE - 1);
-            float4 p = make_float4(sw.x[sl], sw.y[sl], sw.z[sl], sw.w[sl]);
+            const float4 p = k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
             if (lane < nvalid && k.ablate != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wrap);
             whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
@@ -977,7 +983,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             if (k.ablate == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
             if (hd) {
                 int sl = (dhead + dcnt + mask_rank(md)) & (TC_STAGE - 1);
-                st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = r2;
+                dj[sl] = (uint32_t)j; dr2[sl] = r2;
             }
             dcnt = U(dcnt + (int)__popcll(md));
             if (dcnt >= 64) { convert_d(64); dcnt = U(dcnt - 64); }
@@ -988,7 +994,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                 const uint64_t mw = __ballot(use);
                 if (use) {
                     int sl = (whead + wcnt + mask_rank(mw)) & (TC_STAGE - 1);
-                    sw.x[sl] = p.x; sw.y[sl] = p.y; sw.z[sl] = p.z; sw.w[sl] = p.w;
+                    wj[sl] = (uint32_t)j;
                 }
                 wcnt = U(wcnt + (int)__popcll(mw));
                 if (wcnt >= 64) { convert_w(64); wcnt = U(wcnt - 64); }
