@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--force-comm", action="store_true",
                     help="testing: run the RCCL collectives through a 1-rank communicator")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing: initialise torch.distributed (nccl) and bootstrap the id even with one rank")
     args = ap.parse_args()
 
     # RCCL prints a version banner on stdout when a communicator is created; keep stdout clean for
@@ -88,7 +90,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     uid = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         uid = shard.bootstrap_unique_id(dist, rank, binding.comm_unique_id)
 
@@ -105,7 +108,7 @@ def main():
     step_size = 0.0085                                       # wvt_relax.c:51
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,7 +127,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -179,7 +182,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     g.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
