@@ -102,7 +102,7 @@ struct tc_query {
     int lo[3], nd[3];     /* first cell (unwrapped, may be negative) and cell count per dim */
     bool full[3];         /* the dimension covers the whole ring: no culling there */
     float sf, hpf;        /* cell edge and padded radius (f32 copies for the per-cell culling) */
-    float inv_nyz, inv_nz;
+    float inv_nyz, inv_nz, inv_ny, inv_sf;
     size_t off;           /* table offset of the level */
 };
 
@@ -139,6 +139,47 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
     }
     q.inv_nyz = 1.0f / (float)(q.nd[1] * q.nd[2]);
     q.inv_nz = 1.0f / (float)q.nd[2];
+    q.inv_ny = 1.0f / (float)q.nd[1];
+    q.inv_sf = (float)inv_s;
+}
+
+/* Row (a, b) of the query block = the cells sharing one (x, y) cell coordinate.  Returns the x/y part of
+ * the table index, the first z cell (relative to q.lo[2]) and the number of consecutive z cells the ball
+ * can reach in this row (0 if the row is farther than the padded radius).  Conservative by construction:
+ * a superset of the cells query_cell() keeps. */
+__device__ __forceinline__ void query_row(const tc_query &q, float xi, float yi, float zi, int rw, uint32_t &rowlin,
+                                          int &c0, int &len)
+{
+    const int a = (int)(((float)rw + 0.5f) * q.inv_ny);        /* rw / nd[1] without an integer divide */
+    const int b = rw - a * q.nd[1];
+    const int off[2] = {a, b};
+    const float xs[2] = {xi, yi};
+    float g2 = 0;
+    uint32_t lin = 0;
+    for (int d = 0; d < 2; d++) {
+        int u = q.lo[d] + off[d];
+        if (!q.full[d]) {
+            float clo = (float)u * q.sf, chi = clo + q.sf;
+            float g = xs[d] < clo ? clo - xs[d] : (xs[d] > chi ? xs[d] - chi : 0.0f);
+            g2 += g * g;
+        }
+        lin = (lin << q.L) | (uint32_t)(u & (q.nL - 1));
+    }
+    rowlin = lin << q.L;
+    c0 = 0;
+    len = 0;
+    const float rem = q.hpf * q.hpf - g2;
+    if (rem < 0) return;
+    if (q.full[2]) { len = q.nd[2]; return; }
+    /* z reach of the ball in this row; +-1e-3 cell covers the f32 rounding of coordinate/cell-edge */
+    const float dz = sqrtf(rem) * 1.00001f;
+    int zlo = (int)floorf((zi - dz) * q.inv_sf - 1e-3f) - q.lo[2];
+    int zhi = (int)floorf((zi + dz) * q.inv_sf + 1e-3f) - q.lo[2];
+    if (zlo < 0) zlo = 0;
+    if (zhi > q.nd[2] - 1) zhi = q.nd[2] - 1;
+    if (zhi < zlo) return;
+    c0 = zlo;
+    len = zhi - zlo + 1;
 }
 
 /* Per-lane cell c of the query block: returns the particle run [st,en) (empty if culled). */
@@ -275,9 +316,50 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
     uint32_t ncand = 0;
     uint32_t fill = 0;
 
-    for (int base = 0; base < ncell; base += 64) {
+#ifdef TC_BOX_ENUM
+    const int nrow = 1;
+#else
+    /* Cells are enumerated row by row: one lane per (x, y) row computes the z interval the ball reaches
+     * (no cell outside the ball's bounding cylinder slices is ever touched), a prefix sum over the rows
+     * numbers the cells, and each lane of a 64-cell batch finds its row by bisection over that prefix
+     * held in the lanes themselves (ds_bpermute). */
+    const int nrow = q.nd[0] * q.nd[1];
+#endif
+    for (int rbase = 0; rbase < nrow; rbase += 64) {
+#ifdef TC_BOX_ENUM
+    const int total = ncell;
+#else
+    uint32_t rowlin = 0;
+    int rc0 = 0, rlen = 0;
+    if (rbase + lane < nrow) query_row(q, xi, yi, zi, rbase + lane, rowlin, rc0, rlen);
+    const uint32_t rincl = wave_incl_scan((uint32_t)rlen);
+    const uint32_t rexcl = rincl - (uint32_t)rlen;
+    const int total = __builtin_amdgcn_readlane((int)rincl, 63);
+#endif
+    for (int base = 0; base < total; base += 64) {
         uint32_t st = 0, en = 0;
+#ifdef TC_BOX_ENUM
         if (base + lane < ncell) query_cell(k, q, xi, yi, zi, base + lane, st, en);
+#else
+        {
+            const uint32_t m = (uint32_t)(base + lane);
+            int lo_r = 0, hi_r = 63;                 /* smallest lane r with rincl[r] > m */
+#pragma unroll
+            for (int sstep = 0; sstep < 6; sstep++) {
+                const int mid = (lo_r + hi_r) >> 1;
+                const uint32_t v = __shfl(rincl, mid);
+                if (v > m) hi_r = mid; else lo_r = mid + 1;
+            }
+            const uint32_t rl = __shfl(rowlin, lo_r);
+            const int zc = __shfl(rc0, lo_r) + (int)(m - __shfl(rexcl, lo_r));
+            if (m < (uint32_t)total) {
+                const uint32_t lin = rl | (uint32_t)((q.lo[2] + zc) & (q.nL - 1));
+                const uint2 ce = k.cells[q.off + lin];          /* {~first, last+1}, both 0 when empty */
+                const uint32_t s0 = ~ce.x, e0 = ce.y;
+                if (e0 > s0) { st = s0; en = e0; }
+            }
+        }
+#endif
         const uint32_t cnt = en - st;
 
         /* large cells: the whole wave writes the run of consecutive indices */
@@ -324,6 +406,7 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
                 fill = 0;
             }
         }
+    }
     }
     if (fill) {
         wave_lds_fence();
