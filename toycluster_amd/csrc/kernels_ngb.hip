@@ -35,6 +35,10 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 /* mark a value the program knows to be wave-uniform as such (keeps it in SGPRs, scalar branches) */
 __device__ __forceinline__ int U(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t U(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float U(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
 __device__ __forceinline__ int mask_rank(uint64_t m) /* set bits below this lane */
 {
@@ -983,7 +987,9 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     const tc_density_args &da = a.d;
     const tc_dev_const &k = da.k;
     const int lane = lane_id();
-    const float4 pi = k.pos4[i];
+    /* the particle's own data is wave-uniform: keep it in scalar registers */
+    const float4 pv = k.pos4[i];
+    const float4 pi = make_float4(U(pv.x), U(pv.y), U(pv.z), U(pv.w));
     const float xi = pi.x, yi = pi.y, zi = pi.z;
     const bool do_wvt = a.ustep != nullptr;
 
@@ -1011,11 +1017,11 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     bool wvt_done = false;
 
     if (warm) {
-        const float h0 = d.hsml;
-        const float hb = (float)((double)h0 * 1.23);
-        const float h0sq = h0 * h0, hbsq = hb * hb;
-        const float hw = (float)((double)pi.w * k.boxsize);          /* src/wvt_relax.c:135 */
-        const float hwsq = hw * hw;
+        const float h0 = U(d.hsml);
+        const float hb = U((float)((double)h0 * 1.23));
+        const float h0sq = U(h0 * h0), hbsq = U(hb * hb);
+        const float hw = U((float)((double)pi.w * k.boxsize));       /* src/wvt_relax.c:135 */
+        const float hwsq = U(hw * hw);
         const float R = (do_wvt && hw > hb) ? hw : hb;
         const double boxinv = 1 / k.boxsize;
         const double step_hi = (double)pi.w;                          /* unit step */
