@@ -73,6 +73,8 @@ def lib():
         L.orc_wvt_step.argtypes = [vp, cd, vp, vp, ci]
         L.orc_bfld_from_rotA.argtypes = [vp]
         L.orc_last_stats.argtypes = [vp, C.POINTER(cd), C.POINTER(cd), C.POINTER(cd)]
+        L.orc_reassign_to_halos.argtypes = [ci, vp, cd, ci, C.POINTER(OrcHalo), vp, vp, vp, vp]
+        L.orc_reassign_to_halos.restype = ci
         _lib = L
     return _lib
 
@@ -199,6 +201,30 @@ class Oracle:
         b = np.empty((self.n, 3), np.float32)
         lib().orc_get_bfld(self._h, _p(b))
         return b
+
+
+def _orc_halos(model):
+    halos = (OrcHalo * len(model.halos))()
+    for k, h in enumerate(model.halos):
+        halos[k].mass_gas = h.mass_gas
+        for c in range(3):
+            halos[k].d_com[c] = h.d_com[c]
+        halos[k].rho0, halos[k].beta, halos[k].rcore, halos[k].rcut = h.rho0, h.beta, h.rcore, h.rcut
+        halos[k].have_cuspy = int(h.have_cuspy)
+    return halos
+
+
+def reassign_to_halos(model, pos):
+    """positions.c:264-445 for the gas block: (halo_id[n], perm[n], npart[nhalos]); new[i] = old[perm[i]]."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+    n, nh = pos.shape[0], len(model.halos)
+    rs = np.array([h.r_sample for h in model.halos], np.float64)
+    hid, perm, npart = np.empty(n, np.int32), np.empty(n, np.int64), np.zeros(nh, np.int64)
+    rc = lib().orc_reassign_to_halos(n, _p(pos), model.boxsize, nh, _orc_halos(model), _p(rs), _p(hid), _p(perm),
+                                     _p(npart))
+    if rc:
+        raise RuntimeError("orc_reassign_to_halos: %d" % rc)
+    return hid, perm, npart
 
 
 def format_log_line(l):

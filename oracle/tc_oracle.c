@@ -863,3 +863,75 @@ void orc_bfld_from_rotA(orc_state *s)
         s->bfld[3 * ipart + 2] = (float)b2;
     }
 }
+
+/* ---------------------------------------------------------------- behind the path: halo reassignment */
+
+/* gsl_heapsort_index with its generic signature (sort.c:192 passes compare_int of positions.c:390-396
+ * for the halo ids). */
+typedef int (*orc_cmp_fn)(const void *, const void *);
+
+static void downheap_generic(size_t *p, const char *data, size_t size, size_t N, size_t k, orc_cmp_fn cmp)
+{
+    const size_t pki = p[k];
+    while (k <= N / 2) {
+        size_t j = 2 * k;
+        if (j < N && cmp(data + size * p[j], data + size * p[j + 1]) < 0) j++;
+        if (cmp(data + size * pki, data + size * p[j]) >= 0) break;
+        p[k] = p[j];
+        k = j;
+    }
+    p[k] = pki;
+}
+
+static void heapsort_index_generic(size_t *p, const void *data, size_t count, size_t size, orc_cmp_fn cmp)
+{
+    if (count == 0) return;
+    for (size_t i = 0; i < count; i++) p[i] = i;
+    size_t N = count - 1;
+    size_t k = N / 2;
+    k++;
+    do {
+        k--;
+        downheap_generic(p, (const char *)data, size, N, k, cmp);
+    } while (k > 0);
+    while (N > 0) {
+        size_t tmp = p[0]; p[0] = p[N]; p[N] = tmp;
+        N--;
+        downheap_generic(p, (const char *)data, size, N, 0, cmp);
+    }
+}
+
+static int compare_int(const void *a, const void *b)      /* positions.c:390-396 */
+{
+    const int *x = (const int *)a, *y = (const int *)b;
+    return (*x > *y) - (*x < *y);
+}
+
+/* positions.c:264-331 (gas), Halo_containing positions.c:333-388 (SPH branch), sort_particles
+ * positions.c:399-445.  halo_id[n] as assigned, perm[n] with new[i] = old[perm[i]], npart[nhalos]. */
+int orc_reassign_to_halos(int n, const float *pos, double boxsize, int nhalos, const orc_halo *halos,
+                          const double *r_sample, int32_t *halo_id, int64_t *perm, int64_t *npart)
+{
+    const float boxhalf = 0.5 * boxsize;
+    for (int j = 0; j < nhalos; j++) npart[j] = 0;
+    for (int ip = 0; ip < n; ip++) {
+        float x = pos[3 * ip] - boxhalf, y = pos[3 * ip + 1] - boxhalf, z = pos[3 * ip + 2] - boxhalf;
+        if (x > boxsize || y > boxsize || z > boxsize) return -1;
+        int i = 0;
+        double rho_max = 0;
+        for (int j = 0; j < nhalos; j++) {
+            float r = sqrt((x - halos[j].d_com[0]) * (x - halos[j].d_com[0])
+                           + (y - halos[j].d_com[1]) * (y - halos[j].d_com[1])
+                           + (z - halos[j].d_com[2]) * (z - halos[j].d_com[2]));
+            double rho_gas = gas_density_profile(r, halos[j].rho0, halos[j].beta, halos[j].rcore, halos[j].rcut);
+            if (rho_gas > rho_max && r < r_sample[j]) { i = j; rho_max = rho_gas; }
+        }
+        halo_id[ip] = i;
+        npart[i]++;
+    }
+    size_t *idx = malloc(sizeof(size_t) * (n > 0 ? n : 1));
+    heapsort_index_generic(idx, halo_id, (size_t)n, sizeof(*halo_id), compare_int);
+    for (int i = 0; i < n; i++) perm[i] = (int64_t)idx[i];
+    free(idx);
+    return 0;
+}

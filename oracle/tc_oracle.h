@@ -99,6 +99,10 @@ float orc_wc6(float r, float h);
 float orc_dwc6(float r, float h);
 double orc_wvt_wc6(float r, float h);
 
+/* behind the path: positions.c:264-445 (gas halo reassignment + index heapsort by halo id) */
+int orc_reassign_to_halos(int n, const float *pos, double boxsize, int nhalos, const orc_halo *halos,
+                          const double *r_sample, int32_t *halo_id, int64_t *perm, int64_t *npart);
+
 /* stats of the last orc_find_sph_quantities call */
 void orc_last_stats(const orc_state *s, double *queries_per_part, double *solver_iters_per_part,
                     double *pair_evals_per_part);

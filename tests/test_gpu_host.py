@@ -52,8 +52,13 @@ def test_executable_end_to_end(tmp_path):
     p = g.particles()
     g.close()
     assert len(lines) == len(log)
-    assert np.array_equal(fid, p["id"]) and np.array_equal(fpos, p["pos"])
-    assert np.array_equal(frho, p["rho"]) and np.array_equal(fh, p["hsml"])
+    # Reassign_particles_to_halos (main.c:58) reorders the gas block by halo with the reference's unstable
+    # index heapsort -- even for one halo that is a rotation by one particle, not the identity
+    assert "Particle Distribution after Relaxation" in r.stdout
+    _, perm, npart = hostio.reassign_particles_to_halos(m, p["pos"])
+    assert perm[0] == 1 and perm[-1] == 0 and npart.tolist() == [n]
+    assert np.array_equal(fid, p["id"][perm]) and np.array_equal(fpos, p["pos"][perm])
+    assert np.array_equal(frho, p["rho"][perm]) and np.array_equal(fh, p["hsml"][perm])
     bmag = np.sqrt((fb.astype(np.float64) ** 2).sum(axis=1))
     assert bmag.max() <= 18e-6 * (1 + 1e-6) and bmag.max() > 1e-6          # magnetic_field.c:4,116-122
 
@@ -79,6 +84,29 @@ def test_executable_from_parameter_file_only(tmp_path):
     err = np.abs(rho - rhom) / rhom
     # the survey's probe of the real reference at this configuration: mean 0.057, median ~0.02
     assert 0.03 < err.mean() < 0.09 and np.median(err) < 0.04
+
+
+def test_executable_merger_gas_block_ordered_by_halo(tmp_path):
+    """BASELINE config 2 shape at small N from the parameter file alone: after the relaxation the gas block
+    is grouped by halo (main cluster first, then the bullet; src/positions.c:264-331)."""
+    out = str(tmp_path / "IC_merger")
+    par = open(os.path.join(GOLDEN, "cluster.par")).read().replace("./IC_single_0", out)
+    par = par.replace("Ntotal      1000000", "Ntotal      60000").replace("Mass_Ratio  0 %.3125", "Mass_Ratio  0.3125")
+    parfile = tmp_path / "cluster.par"
+    parfile.write_text(par)
+    r = subprocess.run([hostio.EXE, str(parfile)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "   Main  " in r.stdout and "   Bullet" in r.stdout
+    header, blocks, order = hostio.read_snapshot(out)
+    n = header["npart"][0]
+    fpos = np.frombuffer(blocks["POS "], np.float32).reshape(-1, 3)
+    fid = np.frombuffer(blocks["ID  "], np.int32)
+    assert sorted(fid) == list(range(1, n + 1))
+    m = hostio.setup_to_model(hostio.setup_system(str(parfile)))
+    hid, _, npart = hostio.reassign_particles_to_halos(m, fpos)
+    assert np.all(np.diff(hid) >= 0) and npart[1] > 0.1 * n and npart.sum() == n
+    line = [l for l in r.stdout.splitlines() if l.startswith("   Bullet")][0].split()
+    assert int(line[1]) == npart[1]
 
 
 def test_missing_tag_exits_like_the_reference(tmp_path):

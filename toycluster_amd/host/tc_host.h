@@ -110,10 +110,19 @@ typedef struct {
     int64_t ngas;
     float *pos;                       /* 3*ngas, in [0, boxsize] */
     int32_t *id;                      /* ngas */
+    double *r_sample;                 /* Halo[i].R_Sample[0] per halo, or NULL (optional trailer of the file) */
 } tc_state;
 
 int  tc_read_state(const char *filename, tc_state *st, char *err, size_t errlen);
 int  tc_write_state(const char *filename, const tc_state *st);
 void tc_free_state(tc_state *st);
+
+/* ---- the step behind the hot path: Reassign_particles_to_halos, src/positions.c:264-445 ---- */
+int  tc_halo_containing_gas(const tcgpu_params *par, const tcgpu_halo *halos, const double *r_sample,
+                            float x, float y, float z);
+void tc_heapsort_index_i32(size_t *p, const int32_t *key, size_t n);
+int  tc_reassign_particles_to_halos(const tcgpu_params *par, const tcgpu_halo *halos, const double *r_sample,
+                                    size_t n, const float *pos, int32_t *halo_id, size_t *perm, long long *npart);
+int  tc_permute_rows(void *data, size_t n, size_t width, const size_t *perm);
 
 #endif

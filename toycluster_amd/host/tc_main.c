@@ -14,10 +14,9 @@
  *     Make_magnetic_field();        src/main.c:56  -> A from the model (src/magnetic_field.c:33-69),
  *                                                     tcgpu_bfld_from_rotA_sph(), normalisation
  *                                                     (src/magnetic_field.c:71-131, race-free max)
+ *     Reassign_particles_to_halos(); src/main.c:58 -> tc_reassign_particles_to_halos() (tc_reassign.c)
  *     Write_output();               src/main.c:69  -> tc_write_snapshot()
- * The steps before the hot path (halo set-up, sampling: SURVEY.md 8f-2) are not re-implemented yet;
- * their result -- model scalars, gas positions, ids -- comes from the state file.  Temperatures and
- * velocities (out of scope) are written as zeros.
+ * Temperatures and velocities (out of scope) are written as zeros.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -70,6 +69,9 @@ int main(int argc, char **argv)
         st.id = malloc((size_t)st.ngas * sizeof(int32_t));
         if (!st.halos || !st.pos || !st.id) die(EXIT_FAILURE, "malloc", "out of memory");
         tc_setup_to_model(&S, &st.par, st.halos);
+        st.r_sample = malloc(2 * sizeof(double));
+        if (!st.r_sample) die(EXIT_FAILURE, "malloc", "out of memory");
+        for (int i = 0; i < S.nhalos; i++) st.r_sample[i] = S.halo[i].r_sample[0];
         const char *nt = getenv("OMP_NUM_THREADS");
         printf("Sampling positions "); fflush(stdout);
         tc_sample_gas(&S, nt ? atoi(nt) : 1, st.pos, st.id);
@@ -148,6 +150,26 @@ int main(int argc, char **argv)
         }
     }
     printf("Bfld of %d particles limited to %g G\n", cnt, BMAX);
+
+    /* ---- Reassign_particles_to_halos(): gas block reordered by halo (src/positions.c:264-331) */
+    if (st.r_sample) {
+        int32_t *halo_id = malloc(n * sizeof(int32_t));
+        size_t *perm = malloc(n * sizeof(size_t));
+        long long *np_halo = calloc((size_t)(st.par.nhalos > 0 ? st.par.nhalos : 1), sizeof(long long));
+        if (!halo_id || !perm || !np_halo) die(EXIT_FAILURE, "malloc", "out of memory");
+        rc = tc_reassign_particles_to_halos(&st.par, st.halos, st.r_sample, n, pos, halo_id, perm, np_halo);
+        if (rc) die(EXIT_FAILURE, "Reassign_particles_to_halos", "particle outside the box");
+        rc = tc_permute_rows(pos, n, 3 * sizeof(float), perm) || tc_permute_rows(id, n, sizeof(int32_t), perm)
+             || tc_permute_rows(hsml, n, sizeof(float), perm) || tc_permute_rows(rho, n, sizeof(float), perm)
+             || tc_permute_rows(rhom, n, sizeof(float), perm) || tc_permute_rows(bfld, n, 3 * sizeof(float), perm);
+        if (rc) die(EXIT_FAILURE, "malloc", "out of memory");
+        printf("Particle Distribution after Relaxation :\n   Main     %8lld   %8lld   %8lld  \n",
+               np_halo[0], np_halo[0], 0LL);                              /* gas only: no dark matter here */
+        if (st.par.nhalos > 1) printf("   Bullet   %8lld   %8lld   %8lld  \n", np_halo[1], np_halo[1], 0LL);
+        free(halo_id); free(perm); free(np_halo);
+    } else {
+        printf("State file carries no sampling radii: gas block left in Peano order\n");
+    }
 
     /* ---- Write_output() */
     tc_snapshot s;

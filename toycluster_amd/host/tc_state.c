@@ -2,6 +2,8 @@
  * per-particle SPH fields.  Little-endian, fixed layout:
  *   char magic[8] = "TCSTATE1"; int64 ngas; tcgpu_params par; tcgpu_halo halos[par.nhalos];
  *   float pos[3*ngas]; int32 id[ngas]
+ *   optional trailer: double r_sample[par.nhalos]  (Halo[i].R_Sample[0]; only the halo reassignment
+ *   behind the path reads it, src/positions.c:378)
  */
 #include <stdlib.h>
 #include <string.h>
@@ -11,7 +13,7 @@ static const char MAGIC[8] = {'T', 'C', 'S', 'T', 'A', 'T', 'E', '1'};
 
 void tc_free_state(tc_state *st)
 {
-    free(st->halos); free(st->pos); free(st->id);
+    free(st->halos); free(st->pos); free(st->id); free(st->r_sample);
     memset(st, 0, sizeof(*st));
 }
 
@@ -33,6 +35,13 @@ int tc_read_state(const char *filename, tc_state *st, char *err, size_t errlen)
         ok = ok && fread(st->halos, sizeof(tcgpu_halo), nh, fp) == nh;
         ok = ok && fread(st->pos, sizeof(float), 3 * n, fp) == 3 * n;
         ok = ok && fread(st->id, sizeof(int32_t), n, fp) == n;
+        if (ok && nh) {                                   /* optional trailer */
+            st->r_sample = malloc(nh * sizeof(double));
+            if (!st->r_sample || fread(st->r_sample, sizeof(double), nh, fp) != nh) {
+                free(st->r_sample);
+                st->r_sample = NULL;
+            }
+        }
     }
     fclose(fp);
     if (!ok) { snprintf(err, errlen, "state file %s is malformed", filename); tc_free_state(st); return 2; }
@@ -47,5 +56,6 @@ int tc_write_state(const char *filename, const tc_state *st)
     int ok = fwrite(MAGIC, 1, 8, fp) == 8 && fwrite(&st->ngas, sizeof(int64_t), 1, fp) == 1;
     ok = ok && fwrite(&st->par, sizeof(st->par), 1, fp) == 1 && fwrite(st->halos, sizeof(tcgpu_halo), nh, fp) == nh;
     ok = ok && fwrite(st->pos, sizeof(float), 3 * n, fp) == 3 * n && fwrite(st->id, sizeof(int32_t), n, fp) == n;
+    if (ok && st->r_sample) ok = fwrite(st->r_sample, sizeof(double), nh, fp) == nh;
     return (fclose(fp) == 0 && ok) ? 0 : 6;
 }

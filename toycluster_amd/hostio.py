@@ -167,3 +167,66 @@ def write_state(path, model, pos, ids):
             f.write(bytes(th))
         f.write(pos.tobytes())
         f.write(ids.tobytes())
+        if all(getattr(h, "r_sample", 0) > 0 for h in model.halos):      # optional trailer: Halo[i].R_Sample[0]
+            f.write(np.array([h.r_sample for h in model.halos], "<f8").tobytes())
+
+
+def _model_structs(model):
+    par = TcParams(model.boxsize, model.mpart_gas, model.mtotal, getattr(model, "bfld_eta", 0.5), len(model.halos), 0)
+    halos = (TcHalo * max(1, len(model.halos)))()
+    for k, h in enumerate(model.halos):
+        halos[k].mass_gas = h.mass_gas
+        for c in range(3):
+            halos[k].d_com[c] = h.d_com[c]
+        halos[k].rho0, halos[k].beta, halos[k].rcore, halos[k].rcut = h.rho0, h.beta, h.rcore, h.rcut
+        halos[k].have_cuspy = int(h.have_cuspy)
+    return par, halos
+
+
+def reassign_particles_to_halos(model, pos):
+    """Reassign_particles_to_halos for the gas block (host/tc_reassign.c; src/positions.c:264-445):
+    returns (halo_id[n], perm[n], npart[nhalos]) with new[i] = old[perm[i]]."""
+    L = _lib()
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+    n, nh = pos.shape[0], len(model.halos)
+    par, halos = _model_structs(model)
+    rs = np.array([h.r_sample for h in model.halos], np.float64)
+    hid, perm, npart = np.empty(n, np.int32), np.empty(n, np.uint64), np.zeros(max(nh, 1), np.int64)
+    L.tc_reassign_particles_to_halos.argtypes = [C.POINTER(TcParams), C.POINTER(TcHalo), C.c_void_p, C.c_size_t,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.tc_reassign_particles_to_halos(C.byref(par), halos, rs.ctypes.data, n, pos.ctypes.data, hid.ctypes.data,
+                                          perm.ctypes.data, npart.ctypes.data)
+    if rc:
+        raise RuntimeError("tc_reassign_particles_to_halos: %d" % rc)
+    return hid, perm.astype(np.int64), npart[:nh]
+
+
+def heapsort_index_i32(keys):
+    L = _lib()
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    p = np.empty(len(keys), np.uint64)
+    L.tc_heapsort_index_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tc_heapsort_index_i32(p.ctypes.data, keys.ctypes.data, len(keys))
+    return p.astype(np.int64)
+
+
+class State(C.Structure):
+    _fields_ = [("par", TcParams), ("halos", C.POINTER(TcHalo)), ("ngas", C.c_int64), ("pos", C.POINTER(C.c_float)),
+                ("id", C.POINTER(C.c_int32)), ("r_sample", C.POINTER(C.c_double))]
+
+
+def read_state_header(path):
+    """Load a state file through the C reader (host/tc_state.c) and report what it holds."""
+    L = _lib()
+    st = State()
+    err = C.create_string_buffer(1024)
+    L.tc_read_state.argtypes = [C.c_char_p, C.POINTER(State), C.c_char_p, C.c_size_t]
+    rc = L.tc_read_state(path.encode(), C.byref(st), err, 1024)
+    if rc:
+        raise RuntimeError(err.value.decode())
+    nh = st.par.nhalos
+    out = {"ngas": int(st.ngas), "nhalos": nh, "boxsize": st.par.boxsize, "has_r_sample": bool(st.r_sample),
+           "r_sample": [st.r_sample[i] for i in range(nh)] if st.r_sample else None}
+    L.tc_free_state.argtypes = [C.POINTER(State)]
+    L.tc_free_state(C.byref(st))
+    return out
