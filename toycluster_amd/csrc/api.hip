@@ -14,7 +14,7 @@
 
 static const char *PHASE_NAMES[PH_COUNT] = {"peano_keys", "radix_sort", "permute", "cell_index", "hsml_guess",
                                             "density", "error_sums", "model_hsml", "wvt_sweep", "move",
-                                            "curl", "comm"};
+                                            "curl", "comm", "mirror"};
 
 struct rccl_api {
     void *h;
@@ -109,6 +109,7 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipMalloc(&c->spill, sizeof(double) * (size_t)TC_MAX_PERSISTENT_BLOCKS * TC_WAVES_PER_BLOCK
                                         * (2 * TC_NGBMAX)) == hipSuccess;
     c->fuse = 1;
+    c->rows = 1;
     c->level_shift = 1;                          /* cells of h/4..h/2: fewest candidates per query (tools/fuse_stats.py) */
     ok = ok && hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess;
     ok = ok && hipMemset(c->flags, 0, sizeof(int) * 8) == hipSuccess;
@@ -133,6 +134,9 @@ static void free_particles(tcgpu_ctx *c)
     c->apot = c->bfld = nullptr; c->key = c->key_sorted = nullptr; c->idx = c->idx_sorted = nullptr;
     c->sort_tmp = nullptr; c->cells = nullptr; c->guess = c->hwvt = c->delta = nullptr;
     c->stats = nullptr; c->ngb_buf = nullptr;
+    hipFree(c->cum); hipFree(c->scan_tmp); hipFree(c->mirror); hipFree(c->mirror_idx);
+    c->cum = nullptr; c->scan_tmp = nullptr; c->mirror = nullptr; c->mirror_idx = nullptr;
+    c->cum_alloc = c->mirror_alloc = 0; c->mirror_valid = 0;
     c->cap = 0; c->n = 0; c->ncells_alloc = 0;
 }
 
@@ -232,6 +236,32 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         c->ncells_alloc = ncell;
     }
     c->lmax = lmax;
+    /* row-major mirror: every level whose scan (12 B per cell) is cheap next to the per-particle saving;
+     * queries at a deeper level use the cell-by-cell path */
+    int lmax_rm = lmax;
+    if ((double)n < 0.03 * pow(8.0, (double)lmax)) lmax_rm = lmax - 1;
+    if ((double)lmax_rm * (double)n >= 4.0e9) lmax_rm = 0;          /* slots are 32-bit */
+    if (!c->rows) lmax_rm = 0;
+    c->lmax_rm = lmax_rm;
+    c->mirror_valid = 0;
+    if (lmax_rm > 0) {
+        size_t ncum = tc_level_offset(lmax_rm + 1) + 1, nslot = (size_t)lmax_rm * (size_t)c->cap;
+        if (ncum > c->cum_alloc) {
+            hipFree(c->cum); hipFree(c->scan_tmp);
+            c->cum = nullptr; c->scan_tmp = nullptr; c->cum_alloc = 0;
+            TC_HIP(c, hipMalloc(&c->cum, ncum * sizeof(uint32_t)));
+            if (tc_scan_temp_bytes(ncum, &c->scan_tmp_bytes)) TC_FAIL(c, TCGPU_ERR_HIP, "scan temp query failed");
+            TC_HIP(c, hipMalloc(&c->scan_tmp, c->scan_tmp_bytes ? c->scan_tmp_bytes : 16));
+            c->cum_alloc = ncum;
+        }
+        if (nslot > c->mirror_alloc) {
+            hipFree(c->mirror); hipFree(c->mirror_idx);
+            c->mirror = nullptr; c->mirror_idx = nullptr; c->mirror_alloc = 0;
+            TC_HIP(c, hipMalloc(&c->mirror, nslot * sizeof(float4)));
+            TC_HIP(c, hipMalloc(&c->mirror_idx, nslot * sizeof(uint32_t)));
+            c->mirror_alloc = nslot;
+        }
+    }
     return 0;
 }
 
@@ -274,7 +304,7 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
     TC_HIP(c, hipMemsetAsync(c->rhom[0], 0, cap * sizeof(float), c->stream));
     TC_HIP(c, hipStreamSynchronize(c->stream));
     c->keys_valid = 0;
-    c->index_valid = 0;
+    c->index_valid = 0; c->mirror_valid = 0;
     c->ustep_valid = 0;
     c->need_guess = 1;
     if (hsml) {                                   /* warm start: the guess is only read where hsml == 0 */
@@ -464,7 +494,7 @@ extern "C" int tcgpu_sort_particles_by_peano_key(tcgpu_ctx *c)
     if (s) TC_FAIL(c, TCGPU_ERR_HIP, "radix sort failed");
     if ((rc = tc_launch_permute(c))) return rc;
     c->keys_valid = 1;
-    c->index_valid = 0;
+    c->index_valid = 0; c->mirror_valid = 0;
     c->ustep_valid = 0;
     return TCGPU_OK;
 }
@@ -568,6 +598,7 @@ static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess, int with_wv
         /* one gather per particle serves the density solve and (with_wvt) the WVT sweep that
          * follows on the same positions; the sweep needs the model hsml up front */
         if (with_wvt && (rc = tc_launch_model_hsml(c))) return rc;
+        if ((rc = tc_launch_mirror(c))) return rc;
         if ((rc = tc_launch_iter(c, with_wvt))) return rc;
         c->ustep_valid = with_wvt;
     } else if ((rc = tc_launch_density(c))) return rc;
@@ -792,6 +823,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "level_shift")) c->level_shift = (int)value;
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
+    else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = 0; }
     else if (!strcmp(name, "force_comm")) c->force_comm = value != 0;   /* tests: 1-rank RCCL communicator */
     else if (!strcmp(name, "lmax")) {
         if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "lmax must be set before tcgpu_upload_particles");

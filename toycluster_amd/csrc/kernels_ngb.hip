@@ -260,15 +260,20 @@ __device__ __forceinline__ double pair_r_w(float xi, float yi, float zi, float x
     return sqrt(dx * dx + dy * dy + dz * dz);
 }
 
-/* cell edge the query of radius h will use (same level rule as query_setup) */
-__device__ __forceinline__ double query_cell_edge(const tc_dev_const &k, float h)
+/* table level the query of radius h will use (same rule as query_setup) and its cell edge */
+__device__ __forceinline__ int query_level(const tc_dev_const &k, float h)
 {
     double ratio = k.boxsize / (double)h;
     int L = (ratio >= 1.0) ? (ilogb(ratio) + 1) : 1;
     L += k.level_shift;
     if (L < 1) L = 1;
     if (L > k.lmax) L = k.lmax;
-    return k.boxsize / (double)(1 << L);
+    return L;
+}
+
+__device__ __forceinline__ double query_cell_edge(const tc_dev_const &k, float h)
+{
+    return k.boxsize / (double)(1 << query_level(k, h));
 }
 
 /* Consumer: walk the flat index list, four independent gathers in flight per lane. */
@@ -425,6 +430,81 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
         if (body((int)j, p, act)) return ncand;
     }
     return ncand + norph;
+}
+
+/*
+ * Row-run streaming over the row-major mirror (tc_dev_const::cum / mirror): the fast path of the fused
+ * kernel for a ball that does not touch the periodic boundary (every cell coordinate it reaches lies in
+ * [0, 2^L), so a row's z interval is one run of consecutive table entries) at a mirrored level.
+ *
+ * One lane per (x, y) row computes the z interval as query_row() does and reads the two ends of the run
+ * from cum[]; a prefix sum over the run lengths numbers the candidates.  Flat candidate m of run r sits
+ * in slot m + (a_r - excl_r).  That offset is piecewise constant in m, so it is recovered with one more
+ * prefix sum: every run adds its jump (a_r - b_{r-1}) at its first flat position in a 256-entry LDS
+ * window (`heads`, ds_add so that empty runs sharing a position accumulate), and the running sum of the
+ * window is the offset -- about a dozen instructions per 64 candidates, no per-cell table reads, no
+ * per-lane loops.  body(slot, p, active) as in stream_candidates, but `slot` indexes the mirror.
+ */
+template <class Body>
+__device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi, float yi, float zi, float h,
+                                                uint32_t *heads, Body &&body)
+{
+    const int lane = lane_id();
+    tc_query q;
+    query_setup(k, xi, yi, zi, h, q);
+    const uint32_t *cum = k.cum + q.off;
+    const int nrow = q.nd[0] * q.nd[1];
+    uint32_t ncand = 0;
+    for (int rbase = 0; rbase < nrow; rbase += 64) {
+        uint32_t rowlin = 0;
+        int rc0 = 0, rlen = 0;
+        if (rbase + lane < nrow) query_row(q, xi, yi, zi, rbase + lane, rowlin, rc0, rlen);
+        uint32_t ra = 0, rb = 0;
+        if (rlen > 0) {
+            const uint32_t lin0 = rowlin | (uint32_t)(q.lo[2] + rc0);
+            ra = cum[lin0];
+            rb = cum[lin0 + (uint32_t)rlen];
+        }
+        const uint32_t cnt = rb - ra;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t excl = incl - cnt;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t bprev = (uint32_t)__shfl_up((int)rb, 1);
+        if (lane == 0) bprev = 0;
+        const uint32_t jump = ra - bprev;                 /* mod 2^32; the running sum telescopes to a_r - excl_r */
+        ncand += total;
+        if (k.ablate == 1) continue;
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < total; base += 256) {
+            reinterpret_cast<uint4 *>(heads)[lane] = make_uint4(0, 0, 0, 0);
+            wave_lds_fence();
+            if (excl >= base && excl < base + 256 && excl < total) atomicAdd(&heads[excl - base], jump);
+            wave_lds_fence();
+            uint32_t hsum[4], j[4];
+            float4 p[4];
+            bool act[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) hsum[u] = heads[64 * u + lane];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t sc = wave_incl_scan(hsum[u]) + carry;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+                const uint32_t m = base + 64 * u + lane;
+                act[u] = m < total;
+                j[u] = act[u] ? m + sc : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = k.mirror[j[u]];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (base + 64 * u < total) {
+                    if (body(j[u], p[u], act[u])) return ncand;
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+    return ncand;
 }
 
 /* Persistent-grid work assignment, XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs
@@ -760,6 +840,11 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->orphans = c->orphans;
     k->norph = c->norph;
     k->pos4 = c->pos4[c->cur];
+    const bool rm = c->rows && c->mirror_valid && c->lmax_rm > 0;
+    k->cum = rm ? c->cum : nullptr;
+    k->mirror = rm ? c->mirror : nullptr;
+    k->mirror_idx = rm ? c->mirror_idx : nullptr;
+    k->lmax_rm = rm ? c->lmax_rm : 0;
     k->n = (int)c->n;
     int64_t lo = c->rank * c->shard_len, hi = (c->rank + 1) * c->shard_len;
     if (hi > c->n) hi = c->n;
@@ -1030,6 +1115,12 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         const bool wrap = U((int)!((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
                                    && (double)yi <= k.boxsize - ext && (double)zi >= ext
                                    && (double)zi <= k.boxsize - ext)) != 0;
+        /* interior ball at a mirrored level: candidates come as contiguous runs of the row-major mirror
+         * (stream_rows); `j` is then a mirror slot.  No orphan (coordinate == boxsize) can be within R of an
+         * interior particle, so skipping them there changes nothing. */
+        const bool fast = U((int)(!wrap && k.mirror != nullptr && query_level(k, R) <= k.lmax_rm)) != 0;
+        const float4 *src = fast ? k.mirror : k.pos4;
+        const uint32_t pad_j = fast ? 0u : (uint32_t)i;
 
         tc_list2 L;
         L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
@@ -1042,7 +1133,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
             const bool valid = lane < nvalid;
-            const float4 pj = k.pos4[valid ? dj[sl] : (uint32_t)i];
+            const float4 pj = src[valid ? dj[sl] : pad_j];
             const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
             const bool inn = valid && (r2 < h0sq);
             const bool outr = valid && !inn;
@@ -1060,12 +1151,12 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         auto convert_w = [&](int nvalid) {
             wave_lds_fence();
             int sl = (whead + lane) & (TC_STAGE - 1);
-            const float4 p = k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
+            const float4 p = src[lane < nvalid ? wj[sl] : pad_j];
             if (lane < nvalid && k.ablate != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wrap);
             whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
         };
-        d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
+        auto body = [&](uint32_t j, float4 p, bool act) -> bool {
             float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wrap);
             const bool hd = act && (r2 < hbsq);
             const uint64_t md = __ballot(hd);
@@ -1079,7 +1170,12 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             if (do_wvt) {
                 const bool hwv = act && (r2 < hwsq);
                 cw = U(cw + (int)__popcll(__ballot(hwv)));
-                const bool use = hwv && j != i;
+                bool use = hwv;
+                if (fast) {                                   /* the particle itself: the slot whose Peano index is i */
+                    if (use && r2 == 0.0f) use = k.mirror_idx[j] != (uint32_t)i;
+                } else {
+                    use = hwv && j != (uint32_t)i;
+                }
                 const uint64_t mw = __ballot(use);
                 if (use) {
                     int sl = (whead + wcnt + mask_rank(mw)) & (TC_STAGE - 1);
@@ -1089,7 +1185,9 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                 if (wcnt >= 64) { convert_w(64); wcnt = U(wcnt - 64); }
             }
             return cs + co + dcnt >= TC_NGBMAX;
-        });
+        };
+        if (fast) d.ncand += stream_rows(k, xi, yi, zi, R, idx, body);
+        else d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap, body);
         const bool overflow = cs + co + dcnt >= TC_NGBMAX;
         if (!overflow) {
             if (dcnt > 0) convert_d(dcnt);

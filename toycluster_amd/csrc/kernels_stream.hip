@@ -10,6 +10,8 @@
  *   K10 move + wrap           src/wvt_relax.c:177-214
  * One thread per particle, 16-byte coalesced accesses on float4 positions.
  */
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include "tc_ctx.h"
 
 #define TB 256
@@ -178,6 +180,73 @@ int tc_launch_cells(tcgpu_ctx *c)
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     c->index_valid = 1;
+    c->mirror_valid = 0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ K4m row-major mirror
+
+ * The cell table is dense in (x, y, z) with z fastest, so the cells of one (x, y) row that a ball
+ * reaches are consecutive table entries -- but their particles are scattered over the Peano order.
+ * The mirror stores a second copy of the positions in TABLE order (level by level, cell by cell):
+ * cum[] is the exclusive prefix sum of the cell populations over the whole table, cell o owns the
+ * slots [cum[o], cum[o+1]).  A ball query then needs two cum[] reads per row instead of one table
+ * read per cell, and its candidates are contiguous runs of `mirror`. */
+struct tc_cell_count {
+    __device__ uint32_t operator()(const uint2 &ce) const
+    {
+        const uint32_t s0 = ~ce.x, e0 = ce.y;
+        return e0 > s0 ? e0 - s0 : 0u;
+    }
+};
+
+int tc_scan_temp_bytes(size_t ncell, size_t *bytes)
+{
+    size_t b = 0;
+    auto in = rocprim::make_transform_iterator((const uint2 *)nullptr, tc_cell_count());
+    hipError_t e = rocprim::exclusive_scan(nullptr, b, in, (uint32_t *)nullptr, 0u, ncell, rocprim::plus<uint32_t>());
+    *bytes = b;
+    return e == hipSuccess ? 0 : -1;
+}
+
+__global__ __launch_bounds__(TB) void k_mirror(const float4 *__restrict__ pos4, int n, double box, int lmax, int lmax_rm,
+                                               const uint2 *__restrict__ cells, const uint32_t *__restrict__ cum,
+                                               float4 *__restrict__ mirror, uint32_t *__restrict__ mirror_idx)
+{
+    int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos4[i];
+    uint32_t ci[3];
+    bool orphan;
+    cell_coords(p, box, lmax, ci, &orphan);
+    if (orphan) return;                                   /* not in the table (see k_cells) */
+    for (int L = 1; L <= lmax_rm; L++) {
+        const int sh = lmax - L;
+        const size_t nL = (size_t)1 << L;
+        const size_t o = tc_level_offset(L) + (((size_t)(ci[0] >> sh) * nL) + (ci[1] >> sh)) * nL + (ci[2] >> sh);
+        const uint32_t slot = cum[o] + ((uint32_t)i - ~cells[o].x);
+        mirror[slot] = p;
+        mirror_idx[slot] = (uint32_t)i;
+    }
+}
+
+int tc_launch_mirror(tcgpu_ctx *c)
+{
+    c->mirror_valid = 0;
+    if (!c->rows || c->lmax_rm <= 0 || !c->index_valid) return 0;
+    const int n = (int)c->n;
+    const size_t ncell = tc_level_offset(c->lmax_rm + 1) + 1;          /* +1: the end of the last cell */
+    tc_phase_begin(c, PH_MIRROR);
+    auto in = rocprim::make_transform_iterator((const uint2 *)c->cells, tc_cell_count());
+    size_t b = c->scan_tmp_bytes;
+    hipError_t e = rocprim::exclusive_scan(c->scan_tmp, b, in, c->cum, 0u, ncell, rocprim::plus<uint32_t>(), c->stream);
+    if (e == hipSuccess)
+        k_mirror<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->lmax_rm,
+                                                         c->cells, c->cum, c->mirror, c->mirror_idx);
+    tc_phase_end(c);
+    TC_HIP(c, e);
+    TC_HIP(c, hipGetLastError());
+    c->mirror_valid = 1;
     return 0;
 }
 
@@ -401,6 +470,7 @@ int tc_launch_model_hsml(tcgpu_ctx *c)
                                            c->par.nhalos, c->rhom_next, c->hwvt, c->red);
     k_final4<<<1, TB, 0, c->stream>>>(c->red, nb, fin);
     k_scale_hsml<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, fin, c->hwvt);
+    c->mirror_valid = 0;                      /* pos4.w changed */
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -471,7 +541,7 @@ int tc_launch_move(tcgpu_ctx *c)
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     c->keys_valid = 0;
-    c->index_valid = 0;
+    c->index_valid = 0; c->mirror_valid = 0;
     c->ustep_valid = 0;
     return 0;
 }

@@ -22,7 +22,7 @@
 
 enum tc_phase {
     PH_KEYS = 0, PH_SORT, PH_PERMUTE, PH_CELLS, PH_GUESS, PH_DENSITY, PH_ERROR, PH_MODEL_HSML,
-    PH_WVT, PH_MOVE, PH_CURL, PH_COMM, PH_COUNT
+    PH_WVT, PH_MOVE, PH_CURL, PH_COMM, PH_MIRROR, PH_COUNT
 };
 
 /* Constants every neighbour kernel needs; passed by value. */
@@ -35,6 +35,13 @@ struct tc_dev_const {
     const uint32_t *orphans;      /* particles with a coordinate == boxsize (X has bit 63) */
     const int *norph;
     const float4 *pos4;           /* x,y,z,(w = hsml_wvt) in Peano order */
+    /* row-major mirror of the particles (levels 1..lmax_rm; NULL / 0 when not built): every cell of the
+     * dense (x, y, z) table owns the slots [cum[o], cum[o+1]) of `mirror`, cells taken in table order, so a
+     * run of consecutive z cells of one (x, y) row is ONE contiguous slot range */
+    const uint32_t *cum;          /* exclusive prefix sum of the cell populations over the whole table (+1 entry) */
+    const float4 *mirror;         /* positions (w = hsml_wvt) in slot order */
+    const uint32_t *mirror_idx;   /* slot -> Peano index */
+    int lmax_rm;
     int n;                        /* all particles (neighbour candidates) */
     int lo, hi;                   /* [lo,hi): the particles this GPU solves for */
     int ablate;                   /* profiling only: 1 producer only, 2 +predicate, 3 no solver (results invalid) */
@@ -87,6 +94,14 @@ struct tcgpu_ctx {
     uint32_t *orphans;
     int *norph;
     int index_valid;
+    uint32_t *cum;                /* ncells(lmax_rm)+1 */
+    float4 *mirror;               /* lmax_rm x cap */
+    uint32_t *mirror_idx;
+    void *scan_tmp;
+    size_t scan_tmp_bytes, cum_alloc, mirror_alloc;
+    int lmax_rm;                  /* deepest mirrored level (0: none) */
+    int mirror_valid;
+    int rows;                     /* option: use the row-run fast path (default 1) */
     int level_shift;
     int lmax_override;
     int ablate;
@@ -145,6 +160,8 @@ int tc_launch_keys(tcgpu_ctx *c);
 int tc_launch_keys_xyz(tcgpu_ctx *c, int64_t n, const double *d_xyz, uint64_t *d_hi, uint64_t *d_lo);
 int tc_launch_permute(tcgpu_ctx *c);
 int tc_launch_cells(tcgpu_ctx *c);
+int tc_scan_temp_bytes(size_t ncell, size_t *bytes);
+int tc_launch_mirror(tcgpu_ctx *c);             /* cum, mirror, mirror_idx from cells + pos4 (after pos4.w is final) */
 int tc_launch_guess(tcgpu_ctx *c);
 int tc_launch_model(tcgpu_ctx *c, float *d_out);
 int tc_launch_error(tcgpu_ctx *c);              /* -> red[0..2] = sum err, count, max err (over the shard) */
