@@ -479,6 +479,41 @@ def test_out_of_box_coordinate_is_reported(gpu):
 
 # ------------------------------------------------------------------ full-size properties (config 2)
 
+def test_row_run_path_matches_cell_path():
+    """The fused kernel has two candidate producers: cell by cell over the Peano-ordered table (any ball) and
+    run by run over the row-major mirror (interior balls at a mirrored level, the default where it applies).
+    Both visit the same cells, so candidate counts and control flow are identical; only the order of the hit
+    lists -- hence the f64 summation order -- differs."""
+    n = 200_000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=77)
+    out = []
+    for rows in (1, 0):
+        g = binding.TcGpu(0)
+        g.set_option("rows", rows)
+        g.set_option("stats", 1)
+        g.set_option("timing", 1)
+        g.set_model(m)
+        g.upload(pos, ids)
+        log = g.Regularise_sph_particles(max_iter=3)
+        g.Find_sph_quantities()
+        st = g.density_stats()
+        t = g.phase_times()
+        out.append((log, g.particles(), st, t))
+        g.close()
+    (la, pa, sa, ta), (lb, pb, sb, tb) = out
+    assert ta["mirror"][1] > 0 and tb.get("mirror", (0, 0))[1] == 0          # the mirror was built / was not
+    assert sa["candidates"] == sb["candidates"] and sa["queries"] == sb["queries"]
+    assert sa["solver_iters"] == pytest.approx(sb["solver_iters"], rel=1e-5)
+    assert len(la) == len(lb)
+    for a, b in zip(la, lb):
+        assert a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-6)
+    assert np.array_equal(pa["id"], pb["id"])
+    assert (pa["hsml"] == pb["hsml"]).mean() > 0.99 and rel(pa["hsml"], pb["hsml"]).max() < 1e-5
+    assert rel(pa["rho"], pb["rho"]).max() < 1e-5
+    assert (np.abs(pa["pos"] - pb["pos"]).max(axis=1) / pb["hsml"]).max() < 1e-4
+
+
 def test_full_size_properties(gpu):
     """BASELINE config 2 size (2e6 gas, 2-cluster merger): size-independent properties."""
     n = 2_000_000

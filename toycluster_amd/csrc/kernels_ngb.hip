@@ -110,18 +110,35 @@ struct tc_query {
     size_t off;           /* table offset of the level */
 };
 
-__device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, float yi, float zi, float h, tc_query &q)
+/* table level of a query of radius h: floor(log2(box/h)) + 1 + level_shift, clamped to [1, lmax].
+ * floor(log2(box/h)) from the exponents and mantissas of the two numbers (no division). */
+__device__ __forceinline__ int query_level(const tc_dev_const &k, float h)
 {
-    /* level with s < h <= 2s : L = floor(log2(box/h)) + 1 (+ level_shift) */
-    double ratio = k.boxsize / (double)h;
-    int L = (ratio >= 1.0) ? (ilogb(ratio) + 1) : 1;
+    const double hd = (double)h;
+    int L = 1;
+    if (hd <= k.boxsize) {
+        const int eh = __builtin_amdgcn_frexp_exp(hd) - 1;                 /* hd = mh * 2^eh, mh in [1, 2) */
+        const double mh = 2 * __builtin_amdgcn_frexp_mant(hd);
+        L = k.box_exp - eh - (k.box_mant < mh ? 1 : 0) + 1;
+    }
     L += k.level_shift;
     if (L < 1) L = 1;
     if (L > k.lmax) L = k.lmax;
+    return L;
+}
+
+__device__ __forceinline__ double query_cell_edge_at(const tc_dev_const &k, int L)
+{
+    return __builtin_ldexp(k.boxsize, -L);                                 /* box / 2^L, exact */
+}
+
+__device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, float yi, float zi, float h, tc_query &q)
+{
+    const int L = query_level(k, h);
     q.L = L;
     q.nL = 1 << L;
-    const double s = k.boxsize / (double)q.nL;
-    const double inv_s = (double)q.nL / k.boxsize;
+    const double s = query_cell_edge_at(k, L);
+    const double inv_s = (double)q.nL * k.boxinv;
     q.off = tc_level_offset(L);
     /* pad: the f32 predicate can accept pairs a few ulp beyond h, and the per-cell culling below
      * runs in f32 on coordinates of magnitude boxsize (absolute error < 3e-7 boxsize) */
@@ -260,20 +277,10 @@ __device__ __forceinline__ double pair_r_w(float xi, float yi, float zi, float x
     return sqrt(dx * dx + dy * dy + dz * dz);
 }
 
-/* table level the query of radius h will use (same rule as query_setup) and its cell edge */
-__device__ __forceinline__ int query_level(const tc_dev_const &k, float h)
-{
-    double ratio = k.boxsize / (double)h;
-    int L = (ratio >= 1.0) ? (ilogb(ratio) + 1) : 1;
-    L += k.level_shift;
-    if (L < 1) L = 1;
-    if (L > k.lmax) L = k.lmax;
-    return L;
-}
-
+/* cell edge the query of radius h will use */
 __device__ __forceinline__ double query_cell_edge(const tc_dev_const &k, float h)
 {
-    return k.boxsize / (double)(1 << query_level(k, h));
+    return query_cell_edge_at(k, query_level(k, h));
 }
 
 /* Consumer: walk the flat index list, four independent gathers in flight per lane. */
@@ -832,6 +839,10 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->boxsize = c->par.boxsize;
     k->boxhalf = 0.5 * c->par.boxsize;
     k->mpart = c->par.mpart_gas;
+    k->boxinv = 1 / c->par.boxsize;
+    int e2 = 0;
+    k->box_mant = 2 * frexp(c->par.boxsize, &e2);       /* frexp: [0.5, 1) */
+    k->box_exp = e2 - 1;
     k->boxsize_f = (float)c->par.boxsize;               /* src/tree.c:27 */
     k->boxhalf_f = (float)(c->par.boxsize * 0.5);       /* src/tree.c:28 */
     k->lmax = c->lmax;
@@ -940,7 +951,7 @@ __device__ __forceinline__ void wvt_sum(const tc_dev_const &k, int i, const floa
                                         double &d2)
 {
     const int lane = lane_id();
-    const double boxinv = 1 / k.boxsize;
+    const double boxinv = k.boxinv;
     const float hq = (float)((double)pi.w * k.boxsize);      /* src/wvt_relax.c:135 */
     const float hq2 = hq * hq;
 
@@ -1108,17 +1119,18 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         const float hw = U((float)((double)pi.w * k.boxsize));       /* src/wvt_relax.c:135 */
         const float hwsq = U(hw * hw);
         const float R = (do_wvt && hw > hb) ? hw : hb;
-        const double boxinv = 1 / k.boxsize;
+        const double boxinv = k.boxinv;
         const double step_hi = (double)pi.w;                          /* unit step */
         /* every candidate lies in a cell overlapping [x-R', x+R'], i.e. within R' + s of x per coordinate */
-        const double ext = (double)R * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge(k, R);
+        const int qL = query_level(k, R);
+        const double ext = (double)R * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge_at(k, qL);
         const bool wrap = U((int)!((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
                                    && (double)yi <= k.boxsize - ext && (double)zi >= ext
                                    && (double)zi <= k.boxsize - ext)) != 0;
         /* interior ball at a mirrored level: candidates come as contiguous runs of the row-major mirror
          * (stream_rows); `j` is then a mirror slot.  No orphan (coordinate == boxsize) can be within R of an
          * interior particle, so skipping them there changes nothing. */
-        const bool fast = U((int)(!wrap && k.mirror != nullptr && query_level(k, R) <= k.lmax_rm)) != 0;
+        const bool fast = U((int)(!wrap && k.mirror != nullptr && qL <= k.lmax_rm)) != 0;
         const float4 *src = fast ? k.mirror : k.pos4;
         const uint32_t pad_j = fast ? 0u : (uint32_t)i;
 
@@ -1205,18 +1217,20 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             bool solved = false;
             if (k.ablate) {                                            /* profiling only: no solve */
                 solved = true; d.rho = 1; wvt_done = true;
-            } else if (cs >= TC_DESNNGB) {                                    /* first query already has >= 295 */
-                d.nq += 1;
-                L.cs = cs;
-                solved = solve_hsml(L, cs, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair);
-            } else {                                                   /* hsml *= 1.23, second query */
-                d.nq += 2;
-                d.hsml = hb;
-                if (ca >= TC_DESNNGB) {
+            } else {
+                int cnt_use = -1;                                      /* one call site: the solver is large */
+                if (cs >= TC_DESNNGB) {                                /* first query already has >= 295 */
+                    d.nq += 1;
+                    cnt_use = cs;
+                } else {                                               /* hsml *= 1.23, second query */
+                    d.nq += 2;
+                    d.hsml = hb;
+                    if (ca >= TC_DESNNGB) cnt_use = ca;
+                    else d.hsml = (float)((double)hb * 1.23);          /* still too few: third query, plain path */
+                }
+                if (cnt_use >= 0) {
                     L.cs = cs;
-                    solved = solve_hsml(L, ca, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair);
-                } else {
-                    d.hsml = (float)((double)hb * 1.23);               /* still too few: third query, plain path */
+                    solved = solve_hsml(L, cnt_use, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair);
                 }
             }
             if (solved) d.ok = true;

@@ -28,6 +28,9 @@ enum tc_phase {
 /* Constants every neighbour kernel needs; passed by value. */
 struct tc_dev_const {
     double boxsize, boxhalf, mpart;
+    double boxinv;                /* 1 / boxsize */
+    double box_mant;              /* boxsize = box_mant * 2^box_exp, box_mant in [1, 2) */
+    int box_exp;
     float boxsize_f, boxhalf_f;
     int lmax;                     /* deepest table level in use */
     int level_shift;              /* added to floor(log2(box/h))+1 when choosing the query level */
