@@ -142,10 +142,13 @@ def main():
     # process, so the figure measured by `tools/profile_round.sh` (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE passes of this same command) is read from profiles/ when present.
     traffic = None
+    valu_insts = None
     tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
     if os.path.exists(tpath) and world == 1 and args.particles_per_gpu == PER_GPU_PARTICLES:
         try:
-            traffic = json.load(open(tpath))["bytes_per_launch"]
+            tj = json.load(open(tpath))
+            traffic = tj["bytes_per_launch"]
+            valu_insts = tj.get("valu_insts_per_launch")
         except Exception:
             traffic = None
 
@@ -175,7 +178,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": 1e3 * dens_avg, "launches": dens_launch,
                          "algorithmic_bytes_per_particle": BYTES_DENSITY_PER_PARTICLE,
-                         "whole_iteration_GBs": BYTES_ITER_PER_PARTICLE * n_total * args.steps / dt / 1e9 / world},
+                         "whole_iteration_GBs": BYTES_ITER_PER_PARTICLE * n_total * args.steps / dt / 1e9 / world,
+                         # the kernel is VALU-bound, not HBM-bound: wave instructions of one
+                         # launch (rocprofv3 SQ_INSTS_VALU, profiles/) x 4 cycles / (1024 SIMDs x 2.4 GHz) / launch time
+                         "valu_issue_frac": (valu_insts * 4 / (1024 * 2.4e9) / dens_avg) if (valu_insts and dens_avg > 0) else None},
             "cpu_baseline": cpu,
             "phase_ms_per_step": {k: 1e3 * v[0] / args.steps for k, v in phases.items() if v[1]},
         }
