@@ -631,8 +631,8 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         const double norm_h3 = TC_WC6_NORM / (double)(hf * hf * hf);
         const double norm_h4 = TC_WC6_NORM / (double)(hf * hf * hf * hf) * -22.0;
         const double h3 = hsml * hsml * hsml;
-        const double three_h = 3 / hsml;
         const double inv_h = 1 / hsml;
+        const double three_h = 3 * inv_h;
         const double nmpart = -mpart;
         const double fpt_h3 = TC_FOURPITHIRD * h3;
         const tc_fdiv fd = tc_fdiv_setup(hf);
@@ -663,8 +663,8 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
          * a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0 */
         double wkB = 0, rhoB = 0, dRhoB = 0;
         rl.scan(cnt, hsml, [&](double ra, double rb) {
-            ra = ra > hsml ? hsml : ra;
-            rb = rb > hsml ? hsml : rb;
+            ra = fmin(ra, hsml);
+            rb = fmin(rb, hsml);
             term(ra, wkNgb, rho, dRhodHsml);
             term(rb, wkB, rhoB, dRhoB);
         });
