@@ -106,7 +106,7 @@ struct tc_query {
     int lo[3], nd[3];     /* first cell (unwrapped, may be negative) and cell count per dim */
     bool full[3];         /* the dimension covers the whole ring: no culling there */
     float sf, hpf;        /* cell edge and padded radius (f32 copies for the per-cell culling) */
-    float inv_nyz, inv_nz, inv_ny, inv_sf;
+    float inv_ny, inv_sf;
     size_t off;           /* table offset of the level */
 };
 
@@ -158,8 +158,6 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
         if (nd >= q.nL) { nd = q.nL; lo = 0; q.full[d] = true; }
         q.lo[d] = lo; q.nd[d] = nd;
     }
-    q.inv_nyz = 1.0f / (float)(q.nd[1] * q.nd[2]);
-    q.inv_nz = 1.0f / (float)q.nd[2];
     q.inv_ny = 1.0f / (float)q.nd[1];
     q.inv_sf = (float)inv_s;
 }
@@ -167,7 +165,7 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
 /* Row (a, b) of the query block = the cells sharing one (x, y) cell coordinate.  Returns the x/y part of
  * the table index, the first z cell (relative to q.lo[2]) and the number of consecutive z cells the ball
  * can reach in this row (0 if the row is farther than the padded radius).  Conservative by construction:
- * a superset of the cells query_cell() keeps. */
+ * every cell with a point within the padded radius is inside the interval of its row. */
 __device__ __forceinline__ void query_row(const tc_query &q, float xi, float yi, float zi, int rw, uint32_t &rowlin,
                                           int &c0, int &len)
 {
@@ -201,45 +199,6 @@ __device__ __forceinline__ void query_row(const tc_query &q, float xi, float yi,
     if (zhi < zlo) return;
     c0 = zlo;
     len = zhi - zlo + 1;
-}
-
-/* Per-lane cell c of the query block: returns the particle run [st,en) (empty if culled). */
-__device__ __forceinline__ void query_cell(const tc_dev_const &k, const tc_query &q, float xi, float yi, float zi,
-                                           int c, uint32_t &st, uint32_t &en)
-{
-    st = en = 0;
-    /* c -> (a, b, cc) without integer division: (c + 0.5)/n is never within 0.5/n of an integer,
-     * far more than the rounding of the reciprocal multiply (valid while the block has < 2^22 cells) */
-    const int nyz = q.nd[1] * q.nd[2];
-    int a, b, cc;
-    if (q.nd[0] * nyz < (1 << 22)) {
-        a = (int)(((float)c + 0.5f) * q.inv_nyz);
-        int r = c - a * nyz;
-        b = (int)(((float)r + 0.5f) * q.inv_nz);
-        cc = r - b * q.nd[2];
-    } else {
-        a = c / nyz;
-        int r = c - a * nyz;
-        b = r / q.nd[2];
-        cc = r - b * q.nd[2];
-    }
-    const int off[3] = {a, b, cc};
-    const float xs[3] = {xi, yi, zi};
-    float g2 = 0;
-    uint32_t lin = 0;                             /* 3L <= 30 bits */
-    for (int d = 0; d < 3; d++) {
-        int u = q.lo[d] + off[d];                 /* unwrapped cell coordinate */
-        if (!q.full[d]) {
-            float clo = (float)u * q.sf, chi = clo + q.sf;
-            float g = xs[d] < clo ? clo - xs[d] : (xs[d] > chi ? xs[d] - chi : 0.0f);
-            g2 += g * g;
-        }
-        lin = (lin << q.L) | (uint32_t)(u & (q.nL - 1));
-    }
-    if (g2 > q.hpf * q.hpf) return;
-    uint2 ce = k.cells[q.off + lin];            /* {~first, last+1}, both 0 when empty */
-    uint32_t s0 = ~ce.x, e0 = ce.y;
-    if (e0 > s0) { st = s0; en = e0; }
 }
 
 __device__ __forceinline__ bool is_orphan(const tc_dev_const &k, float4 p)
@@ -326,73 +285,83 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
     const int lane = lane_id();
     tc_query q;
     query_setup(k, xi, yi, zi, h, q);
-    const int ncell = q.nd[0] * q.nd[1] * q.nd[2];
     int norph = *k.norph;
     if (norph > TC_MAX_ORPHANS) norph = TC_MAX_ORPHANS;   /* overflow is flagged by k_cells */
     uint32_t ncand = 0;
     uint32_t fill = 0;
 
-#ifdef TC_BOX_ENUM
-    const int nrow = 1;
-#else
     /* Cells are enumerated row by row: one lane per (x, y) row computes the z interval the ball reaches
      * (no cell outside the ball's bounding cylinder slices is ever touched), a prefix sum over the rows
      * numbers the cells, and each lane of a 64-cell batch finds its row by bisection over that prefix
      * held in the lanes themselves (ds_bpermute). */
     const int nrow = q.nd[0] * q.nd[1];
-#endif
     for (int rbase = 0; rbase < nrow; rbase += 64) {
-#ifdef TC_BOX_ENUM
-    const int total = ncell;
-#else
-    uint32_t rowlin = 0;
-    int rc0 = 0, rlen = 0;
-    if (rbase + lane < nrow) query_row(q, xi, yi, zi, rbase + lane, rowlin, rc0, rlen);
-    const uint32_t rincl = wave_incl_scan((uint32_t)rlen);
-    const uint32_t rexcl = rincl - (uint32_t)rlen;
-    const int total = __builtin_amdgcn_readlane((int)rincl, 63);
-#endif
-    for (int base = 0; base < total; base += 64) {
-        uint32_t st = 0, en = 0;
-#ifdef TC_BOX_ENUM
-        if (base + lane < ncell) query_cell(k, q, xi, yi, zi, base + lane, st, en);
-#else
-        {
-            const uint32_t m = (uint32_t)(base + lane);
-            int lo_r = 0, hi_r = 63;                 /* smallest lane r with rincl[r] > m */
-#pragma unroll
-            for (int sstep = 0; sstep < 6; sstep++) {
-                const int mid = (lo_r + hi_r) >> 1;
-                const uint32_t v = __shfl(rincl, mid);
-                if (v > m) hi_r = mid; else lo_r = mid + 1;
+        uint32_t rowlin = 0;
+        int rc0 = 0, rlen = 0;
+        if (rbase + lane < nrow) query_row(q, xi, yi, zi, rbase + lane, rowlin, rc0, rlen);
+        const uint32_t rincl = wave_incl_scan((uint32_t)rlen);
+        const uint32_t rexcl = rincl - (uint32_t)rlen;
+        const int total = __builtin_amdgcn_readlane((int)rincl, 63);
+        for (int base = 0; base < total; base += 64) {
+            uint32_t st = 0, en = 0;
+            {
+                const uint32_t m = (uint32_t)(base + lane);
+                int lo_r = 0, hi_r = 63;                 /* smallest lane r with rincl[r] > m */
+    #pragma unroll
+                for (int sstep = 0; sstep < 6; sstep++) {
+                    const int mid = (lo_r + hi_r) >> 1;
+                    const uint32_t v = __shfl(rincl, mid);
+                    if (v > m) hi_r = mid; else lo_r = mid + 1;
+                }
+                const uint32_t rl = __shfl(rowlin, lo_r);
+                const int zc = __shfl(rc0, lo_r) + (int)(m - __shfl(rexcl, lo_r));
+                if (m < (uint32_t)total) {
+                    const uint32_t lin = rl | (uint32_t)((q.lo[2] + zc) & (q.nL - 1));
+                    const uint2 ce = k.cells[q.off + lin];          /* {~first, last+1}, both 0 when empty */
+                    const uint32_t s0 = ~ce.x, e0 = ce.y;
+                    if (e0 > s0) { st = s0; en = e0; }
+                }
             }
-            const uint32_t rl = __shfl(rowlin, lo_r);
-            const int zc = __shfl(rc0, lo_r) + (int)(m - __shfl(rexcl, lo_r));
-            if (m < (uint32_t)total) {
-                const uint32_t lin = rl | (uint32_t)((q.lo[2] + zc) & (q.nL - 1));
-                const uint2 ce = k.cells[q.off + lin];          /* {~first, last+1}, both 0 when empty */
-                const uint32_t s0 = ~ce.x, e0 = ce.y;
-                if (e0 > s0) { st = s0; en = e0; }
-            }
-        }
-#endif
-        const uint32_t cnt = en - st;
+            const uint32_t cnt = en - st;
 
-        /* large cells: the whole wave writes the run of consecutive indices */
-        uint64_t big = __ballot(cnt > TC_SMALLCELL);
-        while (big) {
-            int l = __builtin_ctzll(big);
-            big &= big - 1;
-            uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)st, l);
-            uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, l);
-            ncand += c0;
-            uint32_t done = 0;
-            while (done < c0) {
-                uint32_t take = min(c0 - done, idxcap - fill);
-                for (uint32_t t = lane; t < take; t += 64) idx[fill + t] = s0 + done + t;
-                fill += take;
-                done += take;
-                if (fill == idxcap) {
+            /* large cells: the whole wave writes the run of consecutive indices */
+            uint64_t big = __ballot(cnt > TC_SMALLCELL);
+            while (big) {
+                int l = __builtin_ctzll(big);
+                big &= big - 1;
+                uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)st, l);
+                uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, l);
+                ncand += c0;
+                uint32_t done = 0;
+                while (done < c0) {
+                    uint32_t take = min(c0 - done, idxcap - fill);
+                    for (uint32_t t = lane; t < take; t += 64) idx[fill + t] = s0 + done + t;
+                    fill += take;
+                    done += take;
+                    if (fill == idxcap) {
+                        wave_lds_fence();
+                        if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
+                        wave_lds_fence();
+                        fill = 0;
+                    }
+                }
+            }
+
+            /* small cells: one lane expands one cell at its prefix-sum offset */
+            uint32_t pend = (cnt <= TC_SMALLCELL) ? cnt : 0;
+            while (__ballot(pend > 0)) {
+                uint32_t incl = wave_incl_scan(pend);
+                uint32_t excl = incl - pend;
+                bool ok = pend > 0 && incl <= idxcap - fill;
+                if (ok)
+                    for (uint32_t t = 0; t < pend; t++) idx[fill + excl + t] = st + t;
+                uint64_t okm = __ballot(ok);
+                uint32_t emitted = 0;
+                if (okm) emitted = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63 - __builtin_clzll(okm));
+                fill += emitted;
+                ncand += emitted;
+                if (ok) pend = 0;
+                if (__ballot(pend > 0)) {                       /* list full: drain it, then go on */
                     wave_lds_fence();
                     if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
                     wave_lds_fence();
@@ -400,29 +369,6 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
                 }
             }
         }
-
-        /* small cells: one lane expands one cell at its prefix-sum offset */
-        uint32_t pend = (cnt <= TC_SMALLCELL) ? cnt : 0;
-        while (__ballot(pend > 0)) {
-            uint32_t incl = wave_incl_scan(pend);
-            uint32_t excl = incl - pend;
-            bool ok = pend > 0 && incl <= idxcap - fill;
-            if (ok)
-                for (uint32_t t = 0; t < pend; t++) idx[fill + excl + t] = st + t;
-            uint64_t okm = __ballot(ok);
-            uint32_t emitted = 0;
-            if (okm) emitted = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63 - __builtin_clzll(okm));
-            fill += emitted;
-            ncand += emitted;
-            if (ok) pend = 0;
-            if (__ballot(pend > 0)) {                       /* list full: drain it, then go on */
-                wave_lds_fence();
-                if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
-                wave_lds_fence();
-                fill = 0;
-            }
-        }
-    }
     }
     if (fill) {
         wave_lds_fence();

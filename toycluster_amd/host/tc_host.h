@@ -77,6 +77,8 @@ typedef struct {
 int tc_write_snapshot(const char *filename, const tc_snapshot *s);
 
 /* ---- stages in front of the hot path: units, cosmology, halo set-up, sampling ---- */
+#define TC_SETUP_MAXHALOS 72           /* 2 clusters + at most 70 subhalos (src/substructure.c:129) */
+
 typedef struct {                      /* the fields of the reference's HaloProperties that Setup() fills */
     double mtotal200, mass200[2];     /* [0] gas, [1] dark matter */
     double c_nfw, r200, rs, a_hernq;
@@ -84,7 +86,7 @@ typedef struct {                      /* the fields of the reference's HaloPrope
     double r_sample[2], mass[2], mtotal, mass_corr_fac;
     double d_com[3];
     long long npart[2];
-    int have_cuspy, pad_;
+    int have_cuspy, is_stripped;
 } tc_halo_setup;
 
 typedef struct {
@@ -92,16 +94,26 @@ typedef struct {
     double unit_length, unit_mass, unit_vel, unit_time;
     double h_100, omega_m, omega_l, h0_cgs, rho_crit, delta;   /* rho_crit at the cluster redshift, Delta_vir */
     int nhalos, pad_;
-    tc_halo_setup halo[2];
+    tc_halo_setup halo[TC_SETUP_MAXHALOS];
     double boxsize, mtotal, mpart[2];
     long long npart[2];
+    /* -DSUBSTRUCTURE state (struct SubhaloData, src/globals.h): filled by tc_setup_substructure */
+    int sub_first, sub_nhalos, subhost, pad2_;
+    double sub_mtotal, sub_mass_fraction, grav_softening;
+    long long sub_npart[2];
 } tc_setup;
 
 /* Set_units + Set_cosmology + Setup (src/unit.c, src/cosmo.c, src/setup.c:21-344), default build options */
 int  tc_setup_system(const tc_parfile *par, tc_setup *out);
-void tc_setup_to_model(const tc_setup *s, tcgpu_params *par, tcgpu_halo *halos /* [2] */);
+void tc_setup_to_model(const tc_setup *s, tcgpu_params *par, tcgpu_halo *halos /* [s->nhalos] */);
+/* Setup_Substructure (src/substructure.c, build option -DSUBSTRUCTURE -DSUBHOST=<subhost>): appends up to 70
+ * subhalos to s->halo[], takes their particles from the host cluster.  `seed` is the calling thread's
+ * erand48 state (the reference draws from thread 0's stream, src/main.c:20-21) and is advanced. */
+int  tc_setup_substructure(tc_setup *s, int subhost, unsigned short seed[3]);
 /* Make_positions (gas), Make_IDs, Shift_Origin: pos f32[3*npart[0]] in [0,boxsize], id i32[npart[0]] */
 int  tc_sample_gas(const tc_setup *s, int nthreads, float *pos, int32_t *id);
+void tc_thread_seed(int tid, unsigned short seed[3]);
+int  tc_sample_gas_seeded(const tc_setup *s, int nthreads, const unsigned short seed0[3], float *pos, int32_t *id);
 
 /* ---- state file ---- */
 typedef struct {

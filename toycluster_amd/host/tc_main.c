@@ -62,19 +62,35 @@ int main(int argc, char **argv)
         for (int i = 0; i < S.nhalos; i++)
             printf("Halo Setup : <%d>\n   R200 = %g kpc  c_nfw = %g  rho0_gas = %g [gadget]  beta = %g  rc = %g kpc  Rcut = %g kpc\n",
                    i, S.halo[i].r200, S.halo[i].c_nfw, S.halo[i].rho0, S.halo[i].beta, S.halo[i].rcore, S.halo[i].rcut);
+        /* -DSUBSTRUCTURE -DSUBHOST=n are compile-time options of the reference (Makefile:17-18); here they
+         * are run-time: TC_SUBSTRUCTURE=1 [TC_SUBHOST=n] in the environment */
+        unsigned short seed0[3];
+        tc_thread_seed(0, seed0);
+        const char *want_sub = getenv("TC_SUBSTRUCTURE");
+        if (want_sub && atoi(want_sub)) {
+            const char *sh = getenv("TC_SUBHOST");
+            const int subhost = sh ? atoi(sh) : 0;
+            printf("\nSubhalos hosted by cluster <%d> \n\n", subhost);              /* src/setup.c:339-341 */
+            int src = tc_setup_substructure(&S, subhost, seed0);
+            if (src) { snprintf(err, sizeof(err), "Setup_Substructure failed (%d)", src); die(EXIT_FAILURE, "setup", err); }
+            printf("\nSubhalo Setup : \n   Total Mass DM   = %g \n   Mass Fraction   = %4.2g\n   Target Fraction = %g \n"
+                   "   Total Number    = %d / %d \n   Total Ngas      = %lld \n   Total NDM       = %lld \n",
+                   S.sub_mtotal, S.sub_mtotal / S.halo[S.subhost].mtotal200, S.sub_mass_fraction, S.sub_nhalos,
+                   S.nhalos, S.sub_npart[0], S.sub_npart[1]);
+        }
         memset(&st, 0, sizeof(st));
         st.ngas = S.npart[0];
-        st.halos = calloc(2, sizeof(tcgpu_halo));
+        st.halos = calloc((size_t)S.nhalos, sizeof(tcgpu_halo));
         st.pos = malloc(3 * (size_t)st.ngas * sizeof(float));
         st.id = malloc((size_t)st.ngas * sizeof(int32_t));
         if (!st.halos || !st.pos || !st.id) die(EXIT_FAILURE, "malloc", "out of memory");
         tc_setup_to_model(&S, &st.par, st.halos);
-        st.r_sample = malloc(2 * sizeof(double));
+        st.r_sample = malloc((size_t)S.nhalos * sizeof(double));
         if (!st.r_sample) die(EXIT_FAILURE, "malloc", "out of memory");
         for (int i = 0; i < S.nhalos; i++) st.r_sample[i] = S.halo[i].r_sample[0];
         const char *nt = getenv("OMP_NUM_THREADS");
         printf("Sampling positions "); fflush(stdout);
-        tc_sample_gas(&S, nt ? atoi(nt) : 1, st.pos, st.id);
+        tc_sample_gas_seeded(&S, nt ? atoi(nt) : 1, seed0, st.pos, st.id);
         printf(" done\n");
     }
     st.par.bfld_eta = par.bfld_eta;

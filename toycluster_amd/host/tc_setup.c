@@ -210,6 +210,8 @@ int tc_setup_system(const tc_parfile *par, tc_setup *S)
         S->npart[0] += H[i].npart[0];
         S->npart[1] += H[i].npart[1];
     }
+    S->grav_softening = pow(pow(H[0].r_sample[1], 3) / par->ntotal, 1 / 3.) / 7;  /* src/setup.c:266-268 */
+    S->sub_first = S->nhalos;                                                    /* src/io.c:500-503 */
     if (Xm) {                                                                    /* src/setup.c:271-287 */
         const double d = 0.9 * (H[0].r200 + H[1].r200);
         H[0].d_com[0] = -1 * H[1].mtotal200 * d / par->mtot200;
@@ -236,6 +238,257 @@ void tc_setup_to_model(const tc_setup *S, tcgpu_params *par, tcgpu_halo *halos)
     }
 }
 
+/* ---------------------------------------------------------------- substructure
+ *
+ * Setup_Substructure, src/substructure.c:31-114 with its helpers (:116-558), build options
+ * -DSUBSTRUCTURE -DSUBHOST=<subhost>, without SLOW_SUBSTRUCTURE / ADD_THIRD_SUBHALO / THIRD_HALO_ONLY /
+ * REPORTSUBHALOS.  Subhalo bulk velocities (set_subhalo_bulkvel, :560-610) belong to the velocity stage,
+ * which is out of scope; their four erand48 draws per subhalo are still consumed so that the stream
+ * stays aligned with the reference's.
+ */
+#define DESNNGB_HOST 295                         /* src/globals.h:48 */
+#define MIN_DENSITY_CONTRAST 3                   /* src/substructure.c:8 */
+
+static double hernquist_density(double m, double a, double r)                  /* src/setup.c:715-718 */
+{
+    return m / (2 * PI) * a / (r * (r + a) * (r + a) * (r + a));
+}
+
+static double sub_mass_function(const tc_setup *S, double m)                    /* src/substructure.c:471-482 */
+{
+    const double cc = 1, Am = 9.33e-4, alpha = -0.9, beta = 12.2715;
+    const double z = S->par.redshift;
+    const double mSub = m * S->unit_mass / MSOL2CGS;
+    const double mHost = S->halo[S->subhost].mass200[1] * S->unit_mass / MSOL2CGS;
+    const double x = mSub / mHost;
+    return mHost * sqrt(1 + z) * cc * Am * pow(mSub, alpha) * exp(-beta * x * x * x);
+}
+
+static double sub_number_density(const tc_setup *S, double r)                   /* src/substructure.c:495-500 */
+{
+    const double ac = 0.244 * S->halo[S->subhost].c_nfw, alpha = 2, beta = 2.75;
+    return (1 + ac) * pow(r, beta) / (1 + ac * pow(r, alpha));
+}
+
+static double sub_inverted_number_density(const tc_setup *S, double q)          /* src/substructure.c:502-519 */
+{
+    double left = 0, right = S->halo[S->subhost].r200, r = 0, delta = 1e300;
+    while (fabs(delta) > 1e-3) {
+        r = left + 0.5 * (right - left);
+        delta = sub_number_density(S, r) - q;
+        if (delta > 0) right = r; else left = r;
+    }
+    return r;
+}
+
+static double nfw_mass(const tc_setup *S, double c_nfw, double rs, double r)    /* src/substructure.c:542-553 */
+{
+    const double delta_s = S->delta / 3 * c_nfw * c_nfw * c_nfw / (log(1 + c_nfw) - c_nfw / (1 + c_nfw));
+    const double rho_crit0 = 3. / 8. / PI / GRAV_CGS * S->h0_cgs * S->h0_cgs;  /* src/cosmo.c:20 */
+    const double unit_density = S->unit_mass / (S->unit_length * S->unit_length * S->unit_length);
+    const double rho_s = delta_s * rho_crit0 / unit_density;
+    return 4 * PI * rho_s * rs * rs * rs * (log((rs + r) / rs) - r / (rs + r));
+}
+
+static double nfw_scale_radius(const tc_setup *S, double c_nfw, double M_t, double r)   /* src/substructure.c:521-540 */
+{
+    double left = 0, right = 10 * S->halo[S->subhost].r_sample[0], rs = 0, delta = 1e300;
+    int guard = 0;
+    while (fabs(delta) > 1e-3) {
+        rs = left + 0.5 * (right - left);
+        delta = nfw_mass(S, c_nfw, rs, r) - M_t;
+        if (delta > 0) right = rs; else left = rs;
+        if (++guard > 4000) break;                       /* the reference has no guard */
+    }
+    return rs;
+}
+
+static double sub_sampling_radius(const tc_setup *S, int i, double d)           /* src/substructure.c:434-456 */
+{
+    const double rho_host = hernquist_density(S->halo[0].mass[1], S->halo[0].a_hernq, d);
+    const double m = S->halo[i].mass[1], a = S->halo[i].a_hernq;
+    /* With a == 0 (see set_subhalo_properties) the subhalo density is 0 everywhere, delta stays -1 and r
+     * halves until it underflows to 0, where 0/0 = NaN ends the loop: the reference then returns 0. */
+    double left = 0, right = 10 * S->halo[0].r200, r = 0, delta = 1e300;
+    int guard = 0;
+    while (fabs(delta) > 1e-3) {
+        r = left + 0.5 * (right - left);
+        delta = (hernquist_density(m, a, r) - rho_host) / rho_host;
+        if (delta < 0) right = r; else left = r;
+        if (++guard > 4000) break;
+    }
+    return r;
+}
+
+static double sub_tidal_radius(const tc_setup *S, int i, double r)              /* src/substructure.c:459-468 */
+{
+    const double m_sub = S->halo[i].mass[1], m_host = S->halo[S->subhost].mass200[1], a = S->halo[S->subhost].a_hernq;
+    const double fac = 2 * r * r / ((a + r) * (a + r)) * (1 - a * r * r / ((r + a) * (r + a) * (r + a)));
+    return r * pow(m_sub / (m_host * fac), 1.0 / 3.0);
+}
+
+static double sub_concentration(const tc_setup *S, int i)                       /* src/setup.c:529-549 */
+{
+    const double mass_sub = S->halo[i].mass[1] * S->unit_mass / MSOL2CGS;
+    const double aR = 0.237, c1 = 232.15, c2 = -181.74, a1 = 0.0146, a2 = 0.008;
+    const tc_halo_setup *host = &S->halo[S->subhost], *h = &S->halo[i];
+    const double dx = host->d_com[0] - h->d_com[0], dy = host->d_com[1] - h->d_com[1], dz = host->d_com[2] - h->d_com[2];
+    const double d_vir = sqrt(dx * dx + dy * dy + dz * dz) / S->halo[0].r200;
+    double c = pow(d_vir, -aR) * (c1 * pow(mass_sub, -a1) + c2 * pow(mass_sub, -a2));
+    return c / (1 + S->par.redshift);
+}
+
+static void set_subhalo_masses(tc_setup *S, unsigned short seed[3])             /* src/substructure.c:116-183 */
+{
+    const tc_halo_setup *host = &S->halo[S->subhost];
+    const double min_mass = 10 * DESNNGB_HOST * (S->mpart[0] + S->mpart[1]);    /* MIN_SUBHALO_MASS, :7 */
+    const double mass_limit = host->mass200[1] * S->sub_mass_fraction;
+    const double qmax = sub_mass_function(S, min_mass) / min_mass;
+    const double max_subhalo_mass = S->sub_mass_fraction * host->mass[1] / 10;
+    int i = S->sub_first;
+    while (S->sub_mtotal < mass_limit && i < 70) {
+        double mDM = 0;
+        int j;
+        for (j = 0; j < 10000; j++) {                                           /* rejection sampling */
+            mDM = min_mass + erand48(seed) * (host->mass200[1] - min_mass);
+            const double q = sub_mass_function(S, mDM) / mDM;
+            const double lower_bound = qmax * erand48(seed);
+            if (mass_limit - S->sub_mtotal < min_mass) { mDM = min_mass; break; }
+            if (S->sub_mtotal + mDM > 1.05 * mass_limit) continue;
+            if (mDM > max_subhalo_mass) continue;
+            if (q >= lower_bound) break;
+        }
+        /* sic: when all 10 000 tries are rejected the loop leaves j == 10000, this test does not fire and the
+         * LAST draw is kept whatever it was (about one subhalo in three at config-4 resolution, where a try
+         * is accepted with p ~ 1e-4) -- the reference's behaviour, kept */
+        if (j == 9999) mDM = min_mass;
+        S->halo[i].mass[1] = mDM;
+        S->sub_mtotal += mDM;
+        S->sub_nhalos++;
+        i++;
+    }
+    /* sic (src/substructure.c:180): with two clusters this is 2 + nsub; with a single cluster (nhalos == 1,
+     * first subhalo at index 1) it is nsub, i.e. the last sampled subhalo is never set up or populated */
+    S->nhalos += i - 2;
+}
+
+static void set_subhalo_position(tc_setup *S, int i, unsigned short seed[3])    /* src/substructure.c:189-220 */
+{
+    const tc_halo_setup *host = &S->halo[S->subhost];
+    const double q = erand48(seed);
+    const double r = host->r200 * sub_inverted_number_density(S, q);
+    const float theta = acos(2 * erand48(seed) - 1);
+    const float phi = 2 * PI * erand48(seed);
+    const double x = r * sin(theta) * cos(phi), y = r * sin(theta) * sin(phi), z = r * cos(theta);
+    S->halo[i].d_com[0] = (float)(x + host->d_com[0]);
+    S->halo[i].d_com[1] = (float)(y + host->d_com[1]);
+    S->halo[i].d_com[2] = (float)(z + host->d_com[2]);
+}
+
+static void set_subhalo_properties(tc_setup *S, int i)                          /* src/substructure.c:278-375 */
+{
+    tc_halo_setup *h = &S->halo[i];
+    const tc_halo_setup *host = &S->halo[S->subhost];
+    const double dx = host->d_com[0] - h->d_com[0], dy = host->d_com[1] - h->d_com[1], dz = host->d_com[2] - h->d_com[2];
+    const double r_i = sqrt(dx * dx + dy * dy + dz * dz);
+    double a = host->a_hernq / 10, r200 = host->r200, c_nfw = 0, rsample = 0;
+    int cnt = 0;
+    for (;;) {
+        const double last_a = a;
+        /* sampling_radius() reads Halo[i].A_hernq, which the reference only assigns after this loop: the
+         * first subhalo set-up sees 0 (calloc), a resampled one its previous value.  Reproduced as is. */
+        rsample = fmax(sub_sampling_radius(S, i, r_i), sub_tidal_radius(S, i, r_i));
+        rsample = fmin(rsample, r200 * 0.5);
+        /* Concentration_parameter() evaluates the Duffy fit on Halo[i].Mtotal200 first; its value is
+         * overwritten by the subhalo fit (src/setup.c:529-549) */
+        c_nfw = sub_concentration(S, i);
+        h->rs = nfw_scale_radius(S, c_nfw, h->mass[1], rsample);
+        a = h->rs * sqrt(2 * (log(1 + c_nfw) - c_nfw / (1 + c_nfw)));
+        r200 = h->rs * c_nfw;
+        if (fabs((last_a - a) / a) < 1e-4) break;
+        if (cnt++ > 100) break;
+    }
+    h->r_sample[0] = h->r_sample[1] = rsample;
+    h->a_hernq = a;
+    h->r200 = r200;
+    h->c_nfw = c_nfw;
+    const double r_strip = 0;
+    h->rcut = 0.6 * h->r_sample[0];
+    h->mass200[1] = nfw_mass(S, c_nfw, h->rs, r200);
+    if (r_i > r_strip) h->mass200[0] = h->mass200[1] / (1 / S->par.baryon_fraction - 1);
+    h->mtotal200 = h->mass200[0] + h->mass200[1];
+    h->mass_corr_fac = 1 / (1 + 2 * a / r200 + (a / r200) * (a / r200));
+    h->beta = 2.0 / 3.0;
+    if (i < 31 && (S->par.cuspy & (1 << i))) { h->rcore = h->rs / 9; h->have_cuspy = 1; }   /* src/setup.c:567-589 */
+    else { h->rcore = h->rs / 3; h->have_cuspy = 0; }
+    const double rc = h->rcore;
+    h->rho0 = h->mass200[0] / (4 * PI * rc * rc * rc) / (r200 / rc - atan(r200 / rc));
+    h->mass[0] = 0;
+    h->is_stripped = 1;
+    if (r_i > r_strip) {
+        mass_profile_t mp;
+        setup_mass_profile(h, &mp);
+        h->is_stripped = 0;
+        h->mass[0] = mass_profile(&mp, h, h->r_sample[0]);
+        spline_free(&mp.m_of_r); spline_free(&mp.r_of_m);
+    }
+    h->mtotal = h->mass[0] + h->mass[1];
+}
+
+static int reject_subhalo(const tc_setup *S, int i)                             /* src/substructure.c:228-270 */
+{
+    int resample = 0;
+    const tc_halo_setup *h = &S->halo[i], *host = &S->halo[S->subhost];
+    for (int j = S->sub_first; j < i; j++) {
+        const double d0 = h->d_com[0] - S->halo[j].d_com[0], d1 = h->d_com[1] - S->halo[j].d_com[1],
+                     d2 = h->d_com[2] - S->halo[j].d_com[2];
+        const double r2 = d0 * d0 + d1 * d1 + d2 * d2, size = h->r_sample[0] + S->halo[j].r_sample[0];
+        if (r2 < size * size) resample = 1;
+    }
+    const double dx = h->d_com[0] - host->d_com[0], dy = h->d_com[1] - host->d_com[1], dz = h->d_com[2] - host->d_com[2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    const double rho_host = hernquist_density(S->halo[0].mass[1], S->halo[0].a_hernq, r);
+    const double rho_sub = hernquist_density(h->mass[1], h->a_hernq, 3 * S->grav_softening);
+    if (rho_sub < rho_host * MIN_DENSITY_CONTRAST) resample = 1;
+    if (r > host->r200) resample = 1;
+    return resample;
+}
+
+int tc_setup_substructure(tc_setup *S, int subhost, unsigned short seed[3])
+{
+    if (subhost < 0 || subhost >= S->nhalos) return 1;
+    if (!(S->par.baryon_fraction > 0)) return 2;
+    S->subhost = subhost;
+    S->sub_first = (S->par.mass_ratio != 0) ? 2 : 1;
+    S->sub_mass_fraction = 0.22 * sqrt(1 + S->par.redshift);                    /* src/substructure.c:485-492 */
+    S->sub_mtotal = 0; S->sub_nhalos = 0; S->sub_npart[0] = S->sub_npart[1] = 0;
+    set_subhalo_masses(S, seed);
+    if (S->nhalos > TC_SETUP_MAXHALOS) return 3;
+    for (int i = S->sub_first; i < S->nhalos; i++) {
+        int tries = 0;
+        do {
+            set_subhalo_position(S, i, seed);
+            set_subhalo_properties(S, i);
+            if (++tries > 100000) return 4;
+        } while (reject_subhalo(S, i));
+        for (int k = 0; k < 4; k++) erand48(seed);      /* set_subhalo_bulkvel's draws, src/substructure.c:572-577 */
+    }
+    /* set_subhalo_particle_numbers, src/substructure.c:378-408 */
+    long long sub_ntotal = 0;
+    for (int i = S->sub_first; i < S->nhalos; i++) {
+        tc_halo_setup *h = &S->halo[i];
+        long long nDM = (long long)round(h->mass[1] / S->mpart[1]);
+        long long nGas = S->mpart[0] == 0 ? 0 : (long long)round(h->mass[0] / S->mpart[0]);
+        h->npart[0] = nGas; h->npart[1] = nDM;
+        sub_ntotal += nGas + nDM;
+        S->sub_npart[0] += nGas; S->sub_npart[1] += nDM;
+    }
+    S->halo[subhost].npart[0] -= S->sub_npart[0];
+    S->halo[subhost].npart[1] -= S->sub_npart[1];
+    (void)sub_ntotal;
+    return (S->halo[subhost].npart[0] < 0 || S->halo[subhost].npart[1] < 0) ? 5 : 0;
+}
+
 /* ---------------------------------------------------------------- sampling */
 
 /* src/positions.c:333-388, gas branch (type 0); arguments arrive as float like in the reference */
@@ -246,6 +499,7 @@ static int halo_containing_gas(const tc_setup *S, float x, float y, float z)
     double rho_max = 0;
     for (int j = 0; j < S->nhalos; j++) {
         const tc_halo_setup *h = &S->halo[j];
+        if (h->is_stripped) continue;                                          /* src/positions.c:369-370 */
         float r = sqrt((x - h->d_com[0]) * (x - h->d_com[0]) + (y - h->d_com[1]) * (y - h->d_com[1])
                        + (z - h->d_com[2]) * (z - h->d_com[2]));
         double rho = profile(r, h);
@@ -259,14 +513,25 @@ static int halo_containing_gas(const tc_setup *S, float x, float y, float z)
  * {0,0,14041981*(tid+1)} truncated to 16 bit, one burn-in draw) and its static loop partition. */
 int tc_sample_gas(const tc_setup *S, int nthreads, float *pos, int32_t *id)
 {
+    return tc_sample_gas_seeded(S, nthreads, NULL, pos, id);
+}
+
+/* src/main.c:20-21 for thread `tid` */
+void tc_thread_seed(int tid, unsigned short seed[3])
+{
+    seed[0] = seed[1] = 0;
+    seed[2] = (unsigned short)(14041981 * (tid + 1));
+    erand48(seed);
+}
+
+/* seed0: state of thread 0's stream if something (the substructure set-up) has drawn from it already */
+int tc_sample_gas_seeded(const tc_setup *S, int nthreads, const unsigned short seed0[3], float *pos, int32_t *id)
+{
     if (nthreads < 1) nthreads = 1;
     const double boxhalf = S->boxsize / 2;
     unsigned short (*seed)[3] = malloc(sizeof(unsigned short[3]) * nthreads);
-    for (int t = 0; t < nthreads; t++) {
-        seed[t][0] = seed[t][1] = 0;
-        seed[t][2] = (unsigned short)(14041981 * (t + 1));
-        erand48(seed[t]);
-    }
+    for (int t = 0; t < nthreads; t++) tc_thread_seed(t, seed[t]);
+    if (seed0) memcpy(seed[0], seed0, sizeof(unsigned short[3]));
     long long base = 0;
     for (int i = 0; i < S->nhalos; i++) {
         const tc_halo_setup *h = &S->halo[i];

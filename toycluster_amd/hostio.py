@@ -34,15 +34,18 @@ class HaloSetup(C.Structure):
                 ("rs", C.c_double), ("a_hernq", C.c_double), ("rho0", C.c_double), ("beta", C.c_double),
                 ("rcore", C.c_double), ("rcut", C.c_double), ("r_sample", C.c_double * 2), ("mass", C.c_double * 2),
                 ("mtotal", C.c_double), ("mass_corr_fac", C.c_double), ("d_com", C.c_double * 3),
-                ("npart", C.c_longlong * 2), ("have_cuspy", C.c_int), ("pad_", C.c_int)]
+                ("npart", C.c_longlong * 2), ("have_cuspy", C.c_int), ("is_stripped", C.c_int)]
 
 
 class Setup(C.Structure):
     _fields_ = [("par", ParFile), ("unit_length", C.c_double), ("unit_mass", C.c_double), ("unit_vel", C.c_double),
                 ("unit_time", C.c_double), ("h_100", C.c_double), ("omega_m", C.c_double), ("omega_l", C.c_double),
                 ("h0_cgs", C.c_double), ("rho_crit", C.c_double), ("delta", C.c_double), ("nhalos", C.c_int),
-                ("pad_", C.c_int), ("halo", HaloSetup * 2), ("boxsize", C.c_double), ("mtotal", C.c_double),
-                ("mpart", C.c_double * 2), ("npart", C.c_longlong * 2)]
+                ("pad_", C.c_int), ("halo", HaloSetup * 72), ("boxsize", C.c_double), ("mtotal", C.c_double),
+                ("mpart", C.c_double * 2), ("npart", C.c_longlong * 2),
+                ("sub_first", C.c_int), ("sub_nhalos", C.c_int), ("subhost", C.c_int), ("pad2_", C.c_int),
+                ("sub_mtotal", C.c_double), ("sub_mass_fraction", C.c_double), ("grav_softening", C.c_double),
+                ("sub_npart", C.c_longlong * 2)]
 
 
 def setup_system(parfile_path, overrides=None):
@@ -62,14 +65,31 @@ def setup_system(parfile_path, overrides=None):
     return s
 
 
-def sample_gas(setup, nthreads=1):
+def sample_gas(setup, nthreads=1, seed0=None):
+    """Make_positions (gas) + Make_IDs + Shift_Origin; `seed0` = thread 0's erand48 state as left by
+    setup_substructure (None: fresh stream)."""
     L = _lib()
     n = int(setup.npart[0])
     pos = np.empty((n, 3), np.float32)
     ids = np.empty(n, np.int32)
-    L.tc_sample_gas.argtypes = [C.POINTER(Setup), C.c_int, C.c_void_p, C.c_void_p]
-    L.tc_sample_gas(C.byref(setup), int(nthreads), pos.ctypes.data, ids.ctypes.data)
+    L.tc_sample_gas_seeded.argtypes = [C.POINTER(Setup), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    s0 = None if seed0 is None else (C.c_ushort * 3)(*seed0)
+    L.tc_sample_gas_seeded(C.byref(setup), int(nthreads), s0, pos.ctypes.data, ids.ctypes.data)
     return pos, ids
+
+
+def setup_substructure(setup, subhost=0):
+    """Setup_Substructure (src/substructure.c; the reference's -DSUBSTRUCTURE -DSUBHOST=n build) on a native
+    set-up, in place.  Returns thread 0's erand48 state afterwards (pass it to sample_gas)."""
+    L = _lib()
+    seed = (C.c_ushort * 3)()
+    L.tc_thread_seed.argtypes = [C.c_int, C.c_void_p]
+    L.tc_thread_seed(0, seed)
+    L.tc_setup_substructure.argtypes = [C.POINTER(Setup), C.c_int, C.c_void_p]
+    rc = L.tc_setup_substructure(C.byref(setup), int(subhost), seed)
+    if rc:
+        raise RuntimeError("tc_setup_substructure: %d" % rc)
+    return tuple(seed)
 
 
 def setup_to_model(setup):
