@@ -479,6 +479,54 @@ def test_out_of_box_coordinate_is_reported(gpu):
 
 # ------------------------------------------------------------------ full-size properties (config 2)
 
+def test_particles_on_the_box_faces(gpu):
+    """Coordinates exactly 0 and exactly boxsize are legal (the wrap of wvt_relax.c:190-212 uses `>`).  A
+    coordinate == boxsize is keyed like 0 (X = 2^63, peano.c:134-136) while the position sits on the far face.
+    The reference's tree places a node by the *position* of the particle that creates it but fills it by *key*
+    (tree.c:297-306, :273-280), so such a particle mis-centres its node and the reference's own ball queries then
+    lose ordinary neighbours stored in it.  That artefact is NOT reproduced: the HIP path returns the exact
+    predicate set (the particle is kept out of the cell table / mirror and tested by brute force), which is what
+    the reference's brute-force twin (wvt_relax.c:296-340) returns.  DESIGN.md section 5."""
+    n = 30000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=31)
+    rng = np.random.default_rng(5)
+    box = np.float32(m.boxsize)
+    for k, i in enumerate(rng.choice(n, 60, replace=False)):
+        pos[i, k % 3] = box if k % 2 else np.float32(0)
+    pos[7] = box                                            # a corner
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    gpu.Find_sph_quantities()
+    gpu.Find_sph_quantities()                               # second pass: warm, i.e. the fused kernel
+    p = gpu.particles()
+    assert np.all(np.isfinite(p["hsml"])) and p["hsml"].min() > 0 and p["rho"].min() > 0
+    P = p["pos"]
+    face = np.where(((P == box) | (P == 0)).any(axis=1))[0]
+    assert len(face) >= 50
+    o = O.Oracle(m, P, p["id"])
+    o.build_tree()
+    tree_differs = 0
+    Pd = P.astype(np.float64)
+    for i in face[:40]:
+        d = Pd - Pd[i]
+        d -= m.boxsize * np.round(d / m.boxsize)
+        r = np.sqrt((d * d).sum(axis=1))
+        for j in [int(i)] + [int(x) for x in np.argsort(r)[1:3]]:        # the face particle and two neighbours
+            h = float(p["hsml"][j])
+            a = gpu.Find_ngb_tree(j, h)
+            assert np.array_equal(a, o.find_ngb_simple(j, h))
+            tree_differs += not np.array_equal(a, o.find_ngb_tree(j, h))
+        # kernel-weighted neighbour number of the face particle itself: 295 +- 0.05 over the true neighbour set
+        h = float(p["hsml"][i])
+        u = np.minimum(r / h, 1.0)
+        w = 1365.0 / (64 * np.pi) / h ** 3 * (1 - u) ** 8 * (1 + 8 * u + 25 * u * u + 32 * u ** 3)
+        assert abs((4.18879032135009765 * w * h ** 3).sum() - 295) < 0.06
+    assert tree_differs > 0          # the reference artefact exists (else this docstring is out of date)
+    log = gpu.Regularise_sph_particles(max_iter=2)          # the whole relaxation path runs with them present
+    assert len(log) == 3 and all(np.isfinite(l["err_mean"]) for l in log) and log[2]["err_mean"] < log[0]["err_mean"]
+
+
 def test_row_run_path_matches_cell_path():
     """The fused kernel has two candidate producers: cell by cell over the Peano-ordered table (any ball) and
     run by run over the row-major mirror (interior balls at a mirrored level, the default where it applies).
