@@ -479,6 +479,51 @@ def test_out_of_box_coordinate_is_reported(gpu):
 
 # ------------------------------------------------------------------ full-size properties (config 2)
 
+def test_ngbmax_overflow_paths(gpu):
+    """A tight clump where the model density is low: thousands of particles have more than NGBMAX = 2360
+    neighbours inside their sweep radius.  The reference truncates such a list to the first 2360 hits in ascending
+    index (tree.c:91-92) without noticing (wvt_relax.c:135), and its density pass divides hsml by 1.24 when a
+    query fills the list (sph.c:42-47).  Plain kernels and the fused kernel's fall-backs against the oracle."""
+    n = 20000
+    m = M.preset("single", n)
+    pos, ids = M.sample_gas(m, n, seed=12)
+    rng = np.random.default_rng(3)
+    c = np.float32(m.boxsize) * np.float32([0.80, 0.78, 0.76])
+    k = 3200
+    pos[:k] = (c + rng.normal(0, 0.004 * m.boxsize, (k, 3))).astype(np.float32)
+    o = O.Oracle(m, pos, ids)
+    o.find_sph_quantities()
+    q1 = o.particles()
+    ohs, ode = o.wvt_step(0.0085, move=False)
+    # the case does what it is meant to do: count sweep neighbours of the clump by brute force
+    P = q1["pos"].astype(np.float64)
+    far = 0
+    for i in np.where(np.abs(P - np.float64(c)).max(axis=1) < 0.004 * m.boxsize)[0][:20]:
+        d = P - P[i]
+        d -= m.boxsize * np.round(d / m.boxsize)
+        far += ((d * d).sum(axis=1) < (float(ohs[i]) * m.boxsize) ** 2).sum() >= 2360
+    assert far >= 10
+
+    gpu.set_model(m)
+    gpu.upload(pos, ids)
+    gpu.Find_sph_quantities()                                   # cold: plain density kernel
+    p1 = gpu.particles()
+    assert np.array_equal(p1["id"], q1["id"])
+    assert rel(p1["hsml"], q1["hsml"]).max() < 1e-6 and rel(p1["rho"], q1["rho"]).max() < 1e-6
+    hs, de = gpu.wvt_step(0.0085, move=False)                   # plain sweep kernel (k_wvt)
+    scale = np.abs(ode).max()
+    assert rel(hs, ohs).max() < 3e-7 and np.abs(de - ode).max() < 2e-6 * scale
+
+    o.find_sph_quantities()                                     # warm pass
+    q2 = o.particles()
+    ohs2, ode2 = o.wvt_step(0.0085, move=False)
+    gpu.density_error()                                         # warm: fused kernel, sweep sums included
+    p2 = gpu.particles()
+    assert rel(p2["hsml"], q2["hsml"]).max() < 1e-6 and rel(p2["rho"], q2["rho"]).max() < 1e-6
+    hs2, de2 = gpu.wvt_step(0.0085, move=False)
+    assert rel(hs2, ohs2).max() < 3e-7 and np.abs(de2 - ode2).max() < 2e-6 * np.abs(ode2).max()
+
+
 def test_particles_on_the_box_faces(gpu):
     """Coordinates exactly 0 and exactly boxsize are legal (the wrap of wvt_relax.c:190-212 uses `>`).  A
     coordinate == boxsize is keyed like 0 (X = 2^63, peano.c:134-136) while the position sits on the far face.
