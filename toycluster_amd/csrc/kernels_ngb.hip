@@ -54,40 +54,65 @@ __device__ __forceinline__ double bcast0(double v)
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
-/* one DPP step of a 64-bit value: lanes without a source (or rows masked out) receive +0.0 */
-#define TC_DPP_F64(v, ctrl, rowmask)                                                                         \
+/* one DPP step of a 64-bit value over all rows: lanes without a source receive +0.0 (bound_ctrl) */
+#define TC_DPP_F64(v, ctrl)                                                                                  \
     __builtin_bit_cast(double,                                                                               \
         ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(__builtin_bit_cast(uint64_t, v) >> 32), \
-                                                         ctrl, rowmask, 0xf, false) << 32)                  \
-        | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)__builtin_bit_cast(uint64_t, v), ctrl, rowmask, 0xf, false))
+                                                         ctrl, 0xf, 0xf, true) << 32)                       \
+        | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)__builtin_bit_cast(uint64_t, v), ctrl, 0xf, 0xf, true))
 
-/* wave sum in registers (DPP row shifts + row broadcasts); the total lands in lane 63 and is
- * returned wave-uniform.  Fixed summation tree => bitwise reproducible run to run. */
+/* wave sum in registers (DPP row shifts + row broadcasts); the total lands in lane 63 and is returned
+ * wave-uniform.  A reduction, not a scan: only lane 63's chain matters, ((row3 + row2) + (row1 + row0)) of the
+ * per-row totals, so every step may run on all rows (no row masks, no zero-initialised temporaries).
+ * Fixed summation tree => bitwise reproducible run to run. */
 __device__ __forceinline__ double wsum(double v)
 {
-    v += TC_DPP_F64(v, 0x111, 0xf);   /* row_shr:1 */
-    v += TC_DPP_F64(v, 0x112, 0xf);   /* row_shr:2 */
-    v += TC_DPP_F64(v, 0x114, 0xf);   /* row_shr:4 */
-    v += TC_DPP_F64(v, 0x118, 0xf);   /* row_shr:8 */
-    v += TC_DPP_F64(v, 0x142, 0xa);   /* row_bcast:15 */
-    v += TC_DPP_F64(v, 0x143, 0xc);   /* row_bcast:31 */
+    v += TC_DPP_F64(v, 0x111);   /* row_shr:1 */
+    v += TC_DPP_F64(v, 0x112);   /* row_shr:2 */
+    v += TC_DPP_F64(v, 0x114);   /* row_shr:4 */
+    v += TC_DPP_F64(v, 0x118);   /* row_shr:8  -> lane 15 of every row holds the row total */
+    v += TC_DPP_F64(v, 0x142);   /* row_bcast:15 -> lane 63: rows 3+2, lane 31: rows 1+0 */
+    v += TC_DPP_F64(v, 0x143);   /* row_bcast:31 -> lane 63: all four rows */
     uint64_t u = __builtin_bit_cast(uint64_t, v);
     uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63);
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
-/* inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (no LDS traffic) */
+/* Inclusive prefix sums over the 64 lanes with fused DPP adds (x += x[lane - k]; masked rows keep x): six VALU
+ * instructions per scan.  Written in assembly because the compiler expands the builtin form into
+ * zero-init + v_mov_dpp + add per step.  A DPP read of a VGPR needs two wait states after the VALU write of
+ * it; the hazard recogniser does not see inside inline assembly, so the single scan carries s_nop 1 and the
+ * four-way version interleaves four independent scans (three instructions between dependent ones).
+ * Requires all 64 lanes active (callers are in wave-uniform control flow). */
+#define TC_SCAN_STEP(r, ctl) "v_add_u32_dpp " r ", " r ", " r " " ctl "\n"
+#define TC_SHR1 "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define TC_SHR2 "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define TC_SHR4 "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define TC_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define TC_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define TC_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   /* row_shr:1 */
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   /* row_shr:2 */
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   /* row_shr:4 */
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   /* row_shr:8 */
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1,3 */
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2,3 */
-    return (uint32_t)x;
+    asm volatile("s_nop 1\n"
+                 TC_SCAN_STEP("%0", TC_SHR1) "s_nop 1\n"
+                 TC_SCAN_STEP("%0", TC_SHR2) "s_nop 1\n"
+                 TC_SCAN_STEP("%0", TC_SHR4) "s_nop 1\n"
+                 TC_SCAN_STEP("%0", TC_SHR8) "s_nop 1\n"
+                 TC_SCAN_STEP("%0", TC_BC15) "s_nop 1\n"
+                 TC_SCAN_STEP("%0", TC_BC31)
+                 : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ void wave_incl_scan4(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
+{
+#define TC_SCAN4(ctl) TC_SCAN_STEP("%0", ctl) TC_SCAN_STEP("%1", ctl) TC_SCAN_STEP("%2", ctl) TC_SCAN_STEP("%3", ctl)
+    asm volatile("s_nop 1\n"
+                 TC_SCAN4(TC_SHR1) TC_SCAN4(TC_SHR2) TC_SCAN4(TC_SHR4) TC_SCAN4(TC_SHR8) TC_SCAN4(TC_BC15) TC_SCAN4(TC_BC31)
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef TC_SCAN4
 }
 
 /* LDS written by some lanes is read by others of the same wave: keep the compiler from
@@ -438,10 +463,11 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
             bool act[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) hsum[u] = heads[64 * u + lane];
+            wave_incl_scan4(hsum[0], hsum[1], hsum[2], hsum[3]);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t sc = wave_incl_scan(hsum[u]) + carry;
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+                const uint32_t sc = hsum[u] + carry;
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)hsum[u], 63);
                 const uint32_t m = base + 64 * u + lane;
                 act[u] = m < total;
                 j[u] = act[u] ? m + sc : 0u;
