@@ -240,7 +240,7 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
      * queries at a deeper level use the cell-by-cell path */
     int lmax_rm = lmax;
     if ((double)n < 0.03 * pow(8.0, (double)lmax)) lmax_rm = lmax - 1;
-    if ((double)lmax_rm * (double)n >= 4.0e9) lmax_rm = 0;          /* slots are 32-bit */
+    if ((double)lmax_rm * (double)(c->cap + 1) >= 4.0e9) lmax_rm = 0; /* slots are 32-bit */
     if (!c->rows) lmax_rm = 0;
     c->lmax_rm = lmax_rm;
     c->mirror_valid = 0;
@@ -257,9 +257,16 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         if (nslot > c->mirror_alloc) {
             hipFree(c->mirror); hipFree(c->mirror_idx);
             c->mirror = nullptr; c->mirror_idx = nullptr; c->mirror_alloc = 0;
-            TC_HIP(c, hipMalloc(&c->mirror, nslot * sizeof(float4)));
-            TC_HIP(c, hipMalloc(&c->mirror_idx, nslot * sizeof(uint32_t)));
+            TC_HIP(c, hipMalloc(&c->mirror, (nslot + 1) * sizeof(float4)));
+            TC_HIP(c, hipMalloc(&c->mirror_idx, (nslot + 1) * sizeof(uint32_t)));
             c->mirror_alloc = nslot;
+            /* one extra slot infinitely far away: padding lanes of a candidate batch load it and fail every
+             * distance test by themselves (no per-lane "active" flag in the predicate) */
+            const float inf = HUGE_VALF;
+            const float4 far = make_float4(inf, inf, inf, 0.0f);
+            const uint32_t none = 0xffffffffu;
+            TC_HIP(c, hipMemcpy(c->mirror + nslot, &far, sizeof(far), hipMemcpyHostToDevice));
+            TC_HIP(c, hipMemcpy(c->mirror_idx + nslot, &none, sizeof(none), hipMemcpyHostToDevice));
         }
     }
     return 0;

@@ -40,6 +40,10 @@ __device__ __forceinline__ float U(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
+/* lane mask of a predicate; the builtin uses the compare's own SGPR pair (HIP's __ballot first turns the
+ * predicate into 0/1 in a VGPR and compares again: two extra VALU instructions per call) */
+__device__ __forceinline__ uint64_t tc_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ int mask_rank(uint64_t m) /* set bits below this lane */
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -350,7 +354,7 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
             const uint32_t cnt = en - st;
 
             /* large cells: the whole wave writes the run of consecutive indices */
-            uint64_t big = __ballot(cnt > TC_SMALLCELL);
+            uint64_t big = tc_ballot(cnt > TC_SMALLCELL);
             while (big) {
                 int l = __builtin_ctzll(big);
                 big &= big - 1;
@@ -374,19 +378,19 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
 
             /* small cells: one lane expands one cell at its prefix-sum offset */
             uint32_t pend = (cnt <= TC_SMALLCELL) ? cnt : 0;
-            while (__ballot(pend > 0)) {
+            while (tc_ballot(pend > 0)) {
                 uint32_t incl = wave_incl_scan(pend);
                 uint32_t excl = incl - pend;
                 bool ok = pend > 0 && incl <= idxcap - fill;
                 if (ok)
                     for (uint32_t t = 0; t < pend; t++) idx[fill + excl + t] = st + t;
-                uint64_t okm = __ballot(ok);
+                uint64_t okm = tc_ballot(ok);
                 uint32_t emitted = 0;
                 if (okm) emitted = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63 - __builtin_clzll(okm));
                 fill += emitted;
                 ncand += emitted;
                 if (ok) pend = 0;
-                if (__ballot(pend > 0)) {                       /* list full: drain it, then go on */
+                if (tc_ballot(pend > 0)) {                       /* list full: drain it, then go on */
                     wave_lds_fence();
                     if (consume_candidates(k, idx, (int)fill, norph, body)) return ncand;
                     wave_lds_fence();
@@ -460,7 +464,6 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
             wave_lds_fence();
             uint32_t hsum[4], j[4];
             float4 p[4];
-            bool act[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) hsum[u] = heads[64 * u + lane];
             wave_incl_scan4(hsum[0], hsum[1], hsum[2], hsum[3]);
@@ -469,15 +472,14 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
                 const uint32_t sc = hsum[u] + carry;
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)hsum[u], 63);
                 const uint32_t m = base + 64 * u + lane;
-                act[u] = m < total;
-                j[u] = act[u] ? m + sc : 0u;
+                j[u] = m < total ? m + sc : k.mirror_pad;       /* padding lanes: the slot at infinity */
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) p[u] = k.mirror[j[u]];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (base + 64 * u < total) {
-                    if (body(j[u], p[u], act[u])) return ncand;
+                    if (body(j[u], p[u], true)) return ncand;
                 }
             }
             wave_lds_fence();
@@ -715,7 +717,7 @@ __device__ __forceinline__ void density_loop(const tc_density_args &a, int i, fl
         d.ncand += stream_candidates(k, xi, yi, zi, hsml, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
             float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2 < h2);
-            uint64_t m = __ballot(hit);
+            uint64_t m = tc_ballot(hit);
             if (k.ablate == 2) { cnt += __popcll(m); return false; }
             if (hit) {
                 int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
@@ -828,6 +830,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->mirror = rm ? c->mirror : nullptr;
     k->mirror_idx = rm ? c->mirror_idx : nullptr;
     k->lmax_rm = rm ? c->lmax_rm : 0;
+    k->mirror_pad = (uint32_t)c->mirror_alloc;
     k->n = (int)c->n;
     int64_t lo = c->rank * c->shard_len, hi = (c->rank + 1) * c->shard_len;
     if (hi > c->n) hi = c->n;
@@ -941,9 +944,9 @@ __device__ __forceinline__ void wvt_sum(const tc_dev_const &k, int i, const floa
     stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
         float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
         bool hit = act && (r2 < hq2);
-        cnt += __popcll(__ballot(hit));
+        cnt += __popcll(tc_ballot(hit));
         bool use = hit && j != i;
-        uint64_t m = __ballot(use);
+        uint64_t m = tc_ballot(use);
         if (use) {
             int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
             st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = p.w;
@@ -965,7 +968,7 @@ __device__ __forceinline__ void wvt_sum(const tc_dev_const &k, int i, const floa
             int cm = 0;
             stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
                 float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
-                cm += __popcll(__ballot(act && (r2 < hq2) && j < mid));
+                cm += __popcll(tc_ballot(act && (r2 < hq2) && j < mid));
                 return false;
             });
             if (cm >= TC_NGBMAX) thi = mid; else tlo = mid;
@@ -1123,7 +1126,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             const bool outr = valid && !inn;
             double r = 0;
             if (valid && k.ablate != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wrap);
-            const uint64_t m_in = __ballot(inn), m_out = __ballot(outr);
+            const uint64_t m_in = tc_ballot(inn), m_out = tc_ballot(outr);
             if (inn) { int slot = cs + mask_rank(m_in); if (slot < TC_NGBMAX) L.in.put(slot, r); }
             if (outr) { int slot = co + mask_rank(m_out); if (slot < TC_NGBMAX) L.out.put(slot, r); }
             cs = U(cs + (int)__popcll(m_in));
@@ -1143,7 +1146,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         auto body = [&](uint32_t j, float4 p, bool act) -> bool {
             float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wrap);
             const bool hd = act && (r2 < hbsq);
-            const uint64_t md = __ballot(hd);
+            const uint64_t md = tc_ballot(hd);
             if (k.ablate == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
             if (hd) {
                 int sl = (dhead + dcnt + mask_rank(md)) & (TC_STAGE - 1);
@@ -1153,14 +1156,14 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             if (dcnt >= 64) { convert_d(64); dcnt = U(dcnt - 64); }
             if (do_wvt) {
                 const bool hwv = act && (r2 < hwsq);
-                cw = U(cw + (int)__popcll(__ballot(hwv)));
+                cw = U(cw + (int)__popcll(tc_ballot(hwv)));
                 bool use = hwv;
                 if (fast) {                                   /* the particle itself: the slot whose Peano index is i */
                     if (use && r2 == 0.0f) use = k.mirror_idx[j] != (uint32_t)i;
                 } else {
                     use = hwv && j != (uint32_t)i;
                 }
-                const uint64_t mw = __ballot(use);
+                const uint64_t mw = tc_ballot(use);
                 if (use) {
                     int sl = (whead + wcnt + mask_rank(mw)) & (TC_STAGE - 1);
                     wj[sl] = (uint32_t)j;
@@ -1290,7 +1293,7 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
         stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
             float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2f < hq2) && j < thi;
-            cnt += __popcll(__ballot(hit));
+            cnt += __popcll(tc_ballot(hit));
             if (hit && j != i) {
                 double dx = (double)pi.x - (double)p.x, dy = (double)pi.y - (double)p.y, dz = (double)pi.z - (double)p.z;
                 if (dx > k.boxhalf) dx -= k.boxsize;
@@ -1323,7 +1326,7 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
             int cm = 0;
             stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
                 float r2f = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
-                cm += __popcll(__ballot(act && (r2f < hq2) && j < mid));
+                cm += __popcll(tc_ballot(act && (r2f < hq2) && j < mid));
                 return false;
             });
             if (cm >= TC_NGBMAX) thi = mid; else tlo = mid;
@@ -1376,7 +1379,7 @@ __global__ __launch_bounds__(64) void k_find_ngb(tc_dev_const k, int i, float hs
     stream_candidates(k, pi.x, pi.y, pi.z, hsml, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
         float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
         bool hit = act && (r2 < h2);
-        uint64_t m = __ballot(hit);
+        uint64_t m = tc_ballot(hit);
         if (hit) out[cnt + mask_rank(m)] = j;
         cnt += __popcll(m);
         return false;

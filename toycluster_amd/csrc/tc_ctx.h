@@ -45,6 +45,7 @@ struct tc_dev_const {
     const float4 *mirror;         /* positions (w = hsml_wvt) in slot order */
     const uint32_t *mirror_idx;   /* slot -> Peano index */
     int lmax_rm;
+    uint32_t mirror_pad;          /* slot holding a position at infinity (padding lanes load it) */
     int n;                        /* all particles (neighbour candidates) */
     int lo, hi;                   /* [lo,hi): the particles this GPU solves for */
     int ablate;                   /* profiling only: 1 producer only, 2 +predicate, 3 no solver (results invalid) */
