@@ -49,6 +49,14 @@ __device__ __forceinline__ int mask_rank(uint64_t m) /* set bits below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
+/* min of two finite doubles in one instruction (fmin() adds a canonicalising v_max per operand) */
+__device__ __forceinline__ double min_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 /* wave-uniform copy of a double (lets the compiler keep dependent control flow scalar) */
 __device__ __forceinline__ double bcast0(double v)
 {
@@ -609,7 +617,8 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         const double three_h = 3 * inv_h;
         const double nmpart = -mpart;
         const double fpt_h3 = TC_FOURPITHIRD * h3;
-        const tc_fdiv fd = tc_fdiv_setup(hf);
+        tc_fdiv fd = tc_fdiv_setup(hf);
+        fd.exact_div = U(fd.exact_div);                     /* one h per wave: a scalar branch, not exec masking */
 
         /* Per-entry arithmetic (src/sph.c:133-153, :426-440), trimmed for the VALU: the f32 quotient
          * u = r/h is still correctly rounded (reciprocal + exact-residual correction); the f64
@@ -637,8 +646,8 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
          * a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0 */
         double wkB = 0, rhoB = 0, dRhoB = 0;
         rl.scan(cnt, hsml, [&](double ra, double rb) {
-            ra = fmin(ra, hsml);
-            rb = fmin(rb, hsml);
+            ra = min_f64(ra, hsml);
+            rb = min_f64(rb, hsml);
             term(ra, wkNgb, rho, dRhodHsml);
             term(rb, wkB, rhoB, dRhoB);
         });
