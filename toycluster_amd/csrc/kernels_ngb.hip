@@ -1136,8 +1136,13 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             double r = 0;
             if (valid && k.ablate != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wrap);
             const uint64_t m_in = tc_ballot(inn), m_out = tc_ballot(outr);
-            if (inn) { int slot = cs + mask_rank(m_in); if (slot < TC_NGBMAX) L.in.put(slot, r); }
-            if (outr) { int slot = co + mask_rank(m_out); if (slot < TC_NGBMAX) L.out.put(slot, r); }
+            if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
+                if (inn) L.in.lds[cs + mask_rank(m_in)] = r;
+                if (outr) L.out.lds[co + mask_rank(m_out)] = r;
+            } else {
+                if (inn) { int slot = cs + mask_rank(m_in); if (slot < TC_NGBMAX) L.in.put(slot, r); }
+                if (outr) { int slot = co + mask_rank(m_out); if (slot < TC_NGBMAX) L.out.put(slot, r); }
+            }
             cs = U(cs + (int)__popcll(m_in));
             co = U(co + (int)__popcll(m_out));
             dhead = U((dhead + 64) & (TC_STAGE - 1));
