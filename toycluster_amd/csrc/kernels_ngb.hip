@@ -23,6 +23,7 @@
  * runs with 64-lane partial sums and butterfly reductions.  Kernels are persistent: a fixed
  * grid of waves strides over the particles, so the spill area is bounded.
  */
+#include <type_traits>
 #include "tc_ctx.h"
 
 #define WPB TC_WAVES_PER_BLOCK
@@ -1115,8 +1116,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
          * (stream_rows); `j` is then a mirror slot.  No orphan (coordinate == boxsize) can be within R of an
          * interior particle, so skipping them there changes nothing. */
         const bool fast = U((int)(!wrap && k.mirror != nullptr && qL <= k.lmax_rm)) != 0;
-        const float4 *src = fast ? k.mirror : k.pos4;
-        const uint32_t pad_j = fast ? 0u : (uint32_t)i;
+        /* the gather below is compiled twice (tag F): on the row-run path nothing wraps, positions come
+         * from the mirror and "self" is the slot whose Peano index is i -- all compile-time there */
 
         tc_list2 L;
         L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
@@ -1125,16 +1126,18 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         int dcnt = 0, dhead = 0, wcnt = 0, whead = 0;
 
         /* 64 staged density hits -> f64 separations -> inner / outer list */
-        auto convert_d = [&](int nvalid) {
+        auto convert_d = [&](auto ftag, int nvalid) {
+            constexpr bool F = decltype(ftag)::value;
+            const bool wr = F ? false : wrap;
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
             const bool valid = lane < nvalid;
-            const float4 pj = src[valid ? dj[sl] : pad_j];
+            const float4 pj = F ? k.mirror[valid ? dj[sl] : 0u] : k.pos4[valid ? dj[sl] : (uint32_t)i];
             const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
             const bool inn = valid && (r2 < h0sq);
             const bool outr = valid && !inn;
             double r = 0;
-            if (valid && k.ablate != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wrap);
+            if (valid && k.ablate != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
             const uint64_t m_in = tc_ballot(inn), m_out = tc_ballot(outr);
             if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
                 if (inn) L.in.lds[cs + mask_rank(m_in)] = r;
@@ -1149,16 +1152,20 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             wave_lds_fence();
         };
         /* 64 staged sweep hits -> pair terms */
-        auto convert_w = [&](int nvalid) {
+        auto convert_w = [&](auto ftag, int nvalid) {
+            constexpr bool F = decltype(ftag)::value;
+            const bool wr = F ? false : wrap;
             wave_lds_fence();
             int sl = (whead + lane) & (TC_STAGE - 1);
-            const float4 p = src[lane < nvalid ? wj[sl] : pad_j];
-            if (lane < nvalid && k.ablate != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wrap);
+            const float4 p = F ? k.mirror[lane < nvalid ? wj[sl] : 0u] : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
+            if (lane < nvalid && k.ablate != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wr);
             whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
         };
-        auto body = [&](uint32_t j, float4 p, bool act) -> bool {
-            float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wrap);
+        auto gather = [&](auto ftag, uint32_t j, float4 p, bool act) -> bool {
+            constexpr bool F = decltype(ftag)::value;
+            const bool wr = F ? false : wrap;
+            float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wr);
             const bool hd = act && (r2 < hbsq);
             const uint64_t md = tc_ballot(hd);
             if (k.ablate == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
@@ -1167,12 +1174,12 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                 dj[sl] = (uint32_t)j; dr2[sl] = r2;
             }
             dcnt = U(dcnt + (int)__popcll(md));
-            if (dcnt >= 64) { convert_d(64); dcnt = U(dcnt - 64); }
+            if (dcnt >= 64) { convert_d(ftag, 64); dcnt = U(dcnt - 64); }
             if (do_wvt) {
                 const bool hwv = act && (r2 < hwsq);
                 cw = U(cw + (int)__popcll(tc_ballot(hwv)));
                 bool use = hwv;
-                if (fast) {                                   /* the particle itself: the slot whose Peano index is i */
+                if (F) {                                      /* the particle itself: the slot whose Peano index is i */
                     if (use && r2 == 0.0f) use = k.mirror_idx[j] != (uint32_t)i;
                 } else {
                     use = hwv && j != (uint32_t)i;
@@ -1183,16 +1190,28 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                     wj[sl] = (uint32_t)j;
                 }
                 wcnt = U(wcnt + (int)__popcll(mw));
-                if (wcnt >= 64) { convert_w(64); wcnt = U(wcnt - 64); }
+                if (wcnt >= 64) { convert_w(ftag, 64); wcnt = U(wcnt - 64); }
             }
             return cs + co + dcnt >= TC_NGBMAX;
         };
-        if (fast) d.ncand += stream_rows(k, xi, yi, zi, R, idx, body);
-        else d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap, body);
-        const bool overflow = cs + co + dcnt >= TC_NGBMAX;
-        if (!overflow) {
-            if (dcnt > 0) convert_d(dcnt);
-            if (do_wvt && wcnt > 0) convert_w(wcnt);
+        bool overflow;
+        if (fast) {
+            const std::true_type F;
+            d.ncand += stream_rows(k, xi, yi, zi, R, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
+            overflow = cs + co + dcnt >= TC_NGBMAX;
+            if (!overflow) {
+                if (dcnt > 0) convert_d(F, dcnt);
+                if (do_wvt && wcnt > 0) convert_w(F, wcnt);
+            }
+        } else {
+            const std::false_type F;
+            d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap,
+                                         [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
+            overflow = cs + co + dcnt >= TC_NGBMAX;
+            if (!overflow) {
+                if (dcnt > 0) convert_d(F, dcnt);
+                if (do_wvt && wcnt > 0) convert_w(F, wcnt);
+            }
         }
         wave_lds_fence();
         const int ca = cs + co;
