@@ -7,7 +7,7 @@ from toycluster_amd import binding, model as M
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 m = M.preset("merger", n)
 pos, ids = M.sample_gas(m, n, seed=14041981)
-for lmax in (0, 8):
+for lmax in (0,):
     g = binding.TcGpu(0)
     g.set_option("timing", 1)
     if lmax:
@@ -31,4 +31,10 @@ for lmax in (0, 8):
         L = np.floor(np.log2(m.boxsize / R)).astype(int) + 1 + 1
         print("hsml/box min %.5f median %.5f max %.4f" % (h.min() / m.boxsize, np.median(h) / m.boxsize, h.max() / m.boxsize))
         print("level histogram (unclamped):", dict(zip(*np.unique(L, return_counts=True))))
+        Lc = np.minimum(L, 9)
+        edge = m.boxsize / 2.0 ** Lc
+        ext = R * (1 + 1e-5) + m.boxsize * 1.2e-5 + edge
+        P = p["pos"].astype(np.float64)
+        wrap = ~((P >= ext[:, None]) & (P <= m.boxsize - ext[:, None])).all(axis=1)
+        print("wrap fraction %.4f, level>8 fraction %.4f, either %.4f" % (wrap.mean(), (L > 8).mean(), (wrap | (L > 8)).mean()))
     g.close()
