@@ -26,6 +26,14 @@
 #include <type_traits>
 #include "tc_ctx.h"
 
+/* Stage ablation for instruction-count profiling (tools/ablate_iter.py) is compiled in only with
+ * -DTC_PROFILE_ABLATE (make ablate -> ../lib/libtcgpu_ablate.so); the product kernels carry no such branches. */
+#ifdef TC_PROFILE_ABLATE
+#define TC_ABLATE(k) ((k).ablate)
+#else
+#define TC_ABLATE(k) 0
+#endif
+
 #define WPB TC_WAVES_PER_BLOCK
 #define TBN (WPB * 64)
 
@@ -48,6 +56,19 @@ __device__ __forceinline__ uint64_t tc_ballot(bool p) { return __builtin_amdgcn_
 __device__ __forceinline__ int mask_rank(uint64_t m) /* set bits below this lane */
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+/* A wave-uniform pointer parked in vector registers.  The kernel runs out of scalar registers and the compiler
+ * spills them into VGPR lanes, paying two v_readlane per use of a 64-bit pointer in the hot loops; a pointer
+ * that already lives in a VGPR pair feeds the address arithmetic directly. */
+template <class T>
+__device__ __forceinline__ const T *vgpr_ptr(const T *p)
+{
+    uint64_t u = (uint64_t)p;
+    uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+    asm volatile("v_mov_b32 %0, %0" : "+v"(lo));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(hi));
+    return (const T *)(((uint64_t)hi << 32) | lo);
 }
 
 /* min of two finite doubles in one instruction (fmin() adds a canonicalising v_max per operand) */
@@ -286,7 +307,7 @@ __device__ __forceinline__ bool consume_candidates(const tc_dev_const &k, const 
                                                    Body &body)
 {
     const int lane = lane_id();
-    if (k.ablate == 1) return false;
+    if (TC_ABLATE(k) == 1) return false;
     for (int c0 = 0; c0 < fill; c0 += 256) {
         uint32_t j[4];
         float4 p[4];
@@ -444,6 +465,7 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
     tc_query q;
     query_setup(k, xi, yi, zi, h, q);
     const uint32_t *cum = k.cum + q.off;
+    const float4 *mirror = vgpr_ptr(k.mirror);
     const int nrow = q.nd[0] * q.nd[1];
     uint32_t ncand = 0;
     for (int rbase = 0; rbase < nrow; rbase += 64) {
@@ -464,7 +486,7 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
         if (lane == 0) bprev = 0;
         const uint32_t jump = ra - bprev;                 /* mod 2^32; the running sum telescopes to a_r - excl_r */
         ncand += total;
-        if (k.ablate == 1) continue;
+        if (TC_ABLATE(k) == 1) continue;
         uint32_t carry = 0;
         for (uint32_t base = 0; base < total; base += 256) {
             reinterpret_cast<uint4 *>(heads)[lane] = make_uint4(0, 0, 0, 0);
@@ -484,7 +506,7 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
                 j[u] = m < total ? m + sc : k.mirror_pad;       /* padding lanes: the slot at infinity */
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = k.mirror[j[u]];
+            for (int u = 0; u < 4; u++) p[u] = mirror[j[u]];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (base + 64 * u < total) {
@@ -728,7 +750,7 @@ __device__ __forceinline__ void density_loop(const tc_density_args &a, int i, fl
             float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
             bool hit = act && (r2 < h2);
             uint64_t m = tc_ballot(hit);
-            if (k.ablate == 2) { cnt += __popcll(m); return false; }
+            if (TC_ABLATE(k) == 2) { cnt += __popcll(m); return false; }
             if (hit) {
                 int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
                 st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z;
@@ -741,8 +763,8 @@ __device__ __forceinline__ void density_loop(const tc_density_args &a, int i, fl
         else cnt += scnt;
         cnt = U(cnt);
         wave_lds_fence();
-        if (k.ablate) {
-            if (k.ablate != 3 || cnt >= TC_DESNNGB) { d.ok = true; break; }
+        if (TC_ABLATE(k)) {
+            if (TC_ABLATE(k) != 3 || cnt >= TC_DESNNGB) { d.ok = true; break; }
             hsml = (float)((double)hsml * 1.23);
             continue;
         }
@@ -1119,6 +1141,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         /* the gather below is compiled twice (tag F): on the row-run path nothing wraps, positions come
          * from the mirror and "self" is the slot whose Peano index is i -- all compile-time there */
 
+        const float4 *vmirror = vgpr_ptr(k.mirror);
         tc_list2 L;
         L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
         L.out.lds = lds_lists + TC_ICAP; L.out.spill = spill + TC_NGBMAX;  L.out.cap = TC_OCAP;
@@ -1132,12 +1155,12 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
             const bool valid = lane < nvalid;
-            const float4 pj = F ? k.mirror[valid ? dj[sl] : 0u] : k.pos4[valid ? dj[sl] : (uint32_t)i];
+            const float4 pj = F ? vmirror[valid ? dj[sl] : 0u] : k.pos4[valid ? dj[sl] : (uint32_t)i];
             const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
             const bool inn = valid && (r2 < h0sq);
             const bool outr = valid && !inn;
             double r = 0;
-            if (valid && k.ablate != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
+            if (valid && TC_ABLATE(k) != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
             const uint64_t m_in = tc_ballot(inn), m_out = tc_ballot(outr);
             if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
                 if (inn) L.in.lds[cs + mask_rank(m_in)] = r;
@@ -1157,8 +1180,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             const bool wr = F ? false : wrap;
             wave_lds_fence();
             int sl = (whead + lane) & (TC_STAGE - 1);
-            const float4 p = F ? k.mirror[lane < nvalid ? wj[sl] : 0u] : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
-            if (lane < nvalid && k.ablate != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wr);
+            const float4 p = F ? vmirror[lane < nvalid ? wj[sl] : 0u] : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
+            if (lane < nvalid && TC_ABLATE(k) != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wr);
             whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
         };
@@ -1168,7 +1191,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wr);
             const bool hd = act && (r2 < hbsq);
             const uint64_t md = tc_ballot(hd);
-            if (k.ablate == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
+            if (TC_ABLATE(k) == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
             if (hd) {
                 int sl = (dhead + dcnt + mask_rank(md)) & (TC_STAGE - 1);
                 dj[sl] = (uint32_t)j; dr2[sl] = r2;
@@ -1223,7 +1246,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             }
             /* src/sph.c:36-64 on the two virtual queries */
             bool solved = false;
-            if (k.ablate) {                                            /* profiling only: no solve */
+            if (TC_ABLATE(k)) {                                            /* profiling only: no solve */
                 solved = true; d.rho = 1; wvt_done = true;
             } else {
                 int cnt_use = -1;                                      /* one call site: the solver is large */
