@@ -3,7 +3,10 @@ Run under `rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace` to get instruction coun
 import sys
 sys.path.insert(0, '.')
 import numpy as np
+import os
 from toycluster_amd import binding, model as M
+# the hooks live in a separate build: make -C toycluster_amd/csrc ablate
+binding.LIB_PATH = os.path.join(os.path.dirname(binding.LIB_PATH), "libtcgpu_ablate.so")
 n = 2_000_000
 m = M.preset("merger", n)
 pos, ids = M.sample_gas(m, n, seed=14041981)

@@ -778,6 +778,7 @@ __device__ __forceinline__ void density_loop(const tc_density_args &a, int i, fl
 }
 
 /* src/sph.c:66-70 */
+template <bool STATS = true>
 __device__ __forceinline__ void density_store(const tc_density_args &a, int i, const tc_dstate &d)
 {
     if (lane_id() != 0) return;
@@ -786,7 +787,7 @@ __device__ __forceinline__ void density_store(const tc_density_args &a, int i, c
     a.hsml_out[i] = d.hsml;
     a.rho_out[i] = d.rho;
     a.vhf_out[i] = varHsmlFac;
-    if (a.stats) {
+    if (STATS && a.stats) {
         a.stats[i] = d.nq;
         a.stats[i + (size_t)a.stats_stride] = d.nit;
         a.stats[i + 2 * (size_t)a.stats_stride] = d.npair;
@@ -1085,6 +1086,9 @@ struct tc_iter_args {
 #define TC_ITER_MINWAVES 4
 #define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 4 * TC_STAGE * sizeof(float))
 
+/* STATS: keep the per-particle work counters (queries, solver iterations, pair evaluations, candidates) that
+ * tcgpu_last_density_stats reports; without them the counters are dead code and cost no scalar registers */
+template <bool STATS>
 __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
 {
     const tc_density_args &da = a.d;
@@ -1271,7 +1275,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     }
 
     if (finite && !d.ok && isfinite(d.hsml)) density_loop(da, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d);
-    if (finite) density_store(da, i, d);
+    if (finite) density_store<STATS>(da, i, d);
 
     if (do_wvt) {
         if (!wvt_done) wvt_sum(k, i, pi, (double)pi.w, da.flags, idx, TC_ITER_IDXCAP, sw, u0, u1, u2);
@@ -1283,6 +1287,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     }
 }
 
+template <bool STATS>
 __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
 {
     __shared__ __align__(16) unsigned char lds_raw[WPB * TC_LDS_PER_WAVE_ITER];
@@ -1291,7 +1296,7 @@ __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
     const int gw = blockIdx.x * WPB + wave;
     double *spill = a.d.spill + (size_t)gw * (2 * TC_NGBMAX);
     const tc_stride ws = wave_stride(a.d.k.lo, a.d.k.hi, wave);
-    for (int i = ws.first; i < ws.end; i += ws.step) iter_one(a, i, mine, spill);
+    for (int i = ws.first; i < ws.end; i += ws.step) iter_one<STATS>(a, i, mine, spill);
 }
 
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
@@ -1312,7 +1317,8 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     int nloc = a.d.k.hi - a.d.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_DENSITY);
-    k_iter<<<grid_for(c, nloc, k_iter), TBN, 0, c->stream>>>(a);
+    if (a.d.stats) k_iter<true><<<grid_for(c, nloc, k_iter<true>), TBN, 0, c->stream>>>(a);
+    else k_iter<false><<<grid_for(c, nloc, k_iter<false>), TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
