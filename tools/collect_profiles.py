@@ -8,7 +8,7 @@ shutil.copy(glob.glob(P + '/trace/*/*_kernel_stats.csv')[0], 'profiles/round1_fi
 shutil.copy(P + '/pmc_summary.txt', 'profiles/round1_final_pmc_summary.txt')
 shutil.copy(P + '/bench_under_trace.json', 'profiles/round1_final_bench_under_trace.json')
 f = glob.glob(P + '/trace/*/*_kernel_trace.csv')[0]
-rows = [r for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith('k_iter')]
+rows = [r for r in csv.DictReader(open(f)) if 'k_iter' in r['Kernel_Name'].split('(')[0]]
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
 b = json.loads([l for l in open(P + '/bench_under_trace.json') if l.startswith('{')][-1])
 out = ["k_iter dispatches of `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`",

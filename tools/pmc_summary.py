@@ -9,7 +9,8 @@ def load(d):
     f = glob.glob(d + '/*/*counter_collection.csv')[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]      # "void k_iter<false>(...)" -> k_iter
+        agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
     return agg
 
 
