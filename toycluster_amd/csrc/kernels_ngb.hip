@@ -1088,7 +1088,7 @@ struct tc_iter_args {
 
 /* STATS: keep the per-particle work counters (queries, solver iterations, pair evaluations, candidates) that
  * tcgpu_last_density_stats reports; without them the counters are dead code and cost no scalar registers */
-template <bool STATS>
+template <bool STATS, bool WVT>
 __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
 {
     const tc_density_args &da = a.d;
@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     const float4 pv = k.pos4[i];
     const float4 pi = make_float4(U(pv.x), U(pv.y), U(pv.z), U(pv.w));
     const float xi = pi.x, yi = pi.y, zi = pi.z;
-    const bool do_wvt = a.ustep != nullptr;
+    constexpr bool do_wvt = WVT;                       /* a.ustep != nullptr */
 
     double *lds_lists = reinterpret_cast<double *>(mine);
     uint32_t *idx = reinterpret_cast<uint32_t *>(lds_lists + TC_ICAP + TC_OCAP);
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     }
 }
 
-template <bool STATS>
+template <bool STATS, bool WVT>
 __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
 {
     __shared__ __align__(16) unsigned char lds_raw[WPB * TC_LDS_PER_WAVE_ITER];
@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
     const int gw = blockIdx.x * WPB + wave;
     double *spill = a.d.spill + (size_t)gw * (2 * TC_NGBMAX);
     const tc_stride ws = wave_stride(a.d.k.lo, a.d.k.hi, wave);
-    for (int i = ws.first; i < ws.end; i += ws.step) iter_one<STATS>(a, i, mine, spill);
+    for (int i = ws.first; i < ws.end; i += ws.step) iter_one<STATS, WVT>(a, i, mine, spill);
 }
 
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
@@ -1317,8 +1317,10 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     int nloc = a.d.k.hi - a.d.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_DENSITY);
-    if (a.d.stats) k_iter<true><<<grid_for(c, nloc, k_iter<true>), TBN, 0, c->stream>>>(a);
-    else k_iter<false><<<grid_for(c, nloc, k_iter<false>), TBN, 0, c->stream>>>(a);
+#define TC_LAUNCH_ITER(S, W) k_iter<S, W><<<grid_for(c, nloc, k_iter<S, W>), TBN, 0, c->stream>>>(a)
+    if (a.d.stats) { if (with_wvt) TC_LAUNCH_ITER(true, true); else TC_LAUNCH_ITER(true, false); }
+    else { if (with_wvt) TC_LAUNCH_ITER(false, true); else TC_LAUNCH_ITER(false, false); }
+#undef TC_LAUNCH_ITER
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
