@@ -151,6 +151,15 @@ int tcgpu_comm_init(tcgpu_ctx *ctx, int rank, int nranks, const uint8_t id[128])
 int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
 
 /* ---- tuning / introspection ------------------------------------------------------- */
+/* Options (defaults in brackets).  None of them changes results beyond the f64 summation order.
+ *   "stats" [0]       keep per-particle work counters for tcgpu_last_density_stats
+ *   "timing" [0]      record HIP events per phase for tcgpu_phase_times
+ *   "fuse" [1]        fused density + sweep kernel; 0 = one plain kernel per reference loop
+ *   "rows" [1]        row-run candidate streaming over the row-major mirror (set before upload)
+ *   "level_shift" [1] cell level finer than the smoothing length by this many octree levels
+ *   "lmax" [auto]     deepest cell-table level (set before upload)
+ *   "force_comm" [0]  tests: run the RCCL calls with a 1-rank communicator
+ *   "ablate" [0]      only honoured by the profiling build libtcgpu_ablate.so (results invalid) */
 int tcgpu_set_option(tcgpu_ctx *ctx, const char *name, double value);
 /* Seconds spent on the device in each phase since the last reset (HIP events on the
  * library's own stream): names/values arrays of length *n (in: capacity, out: used). */
