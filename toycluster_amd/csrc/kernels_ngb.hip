@@ -61,14 +61,32 @@ __device__ __forceinline__ int mask_rank(uint64_t m) /* set bits below this lane
 /* A wave-uniform pointer parked in vector registers.  The kernel runs out of scalar registers and the compiler
  * spills them into VGPR lanes, paying two v_readlane per use of a 64-bit pointer in the hot loops; a pointer
  * that already lives in a VGPR pair feeds the address arithmetic directly. */
+#define TC_GLOBAL __attribute__((address_space(1)))
 template <class T>
-__device__ __forceinline__ const T *vgpr_ptr(const T *p)
+__device__ __forceinline__ const TC_GLOBAL T *vgpr_ptr(const T *p)
 {
     uint64_t u = (uint64_t)p;
     uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
     asm volatile("v_mov_b32 %0, %0" : "+v"(lo));
     asm volatile("v_mov_b32 %0, %0" : "+v"(hi));
-    return (const T *)(((uint64_t)hi << 32) | lo);
+    /* device memory: keep the global address space so that the loads are global_load, not flat_load */
+    return (const TC_GLOBAL T *)(((uint64_t)hi << 32) | lo);
+}
+
+/* float4 loads through such a pointer (HIP's float4 class has no address-space-qualified copy) */
+typedef float tc_f4n __attribute__((ext_vector_type(4)));
+typedef const TC_GLOBAL tc_f4n *tc_gpos;
+__device__ __forceinline__ tc_gpos vgpr_pos(const float4 *p) { return (tc_gpos)vgpr_ptr(reinterpret_cast<const tc_f4n *>(p)); }
+__device__ __forceinline__ float4 ld4(tc_gpos p, uint32_t j)
+{
+    const tc_f4n v = p[j];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ uint32_t vgpr_u32(uint32_t v)
+{
+    asm volatile("v_mov_b32 %0, %0" : "+v"(v));
+    return v;
 }
 
 /* min of two finite doubles in one instruction (fmin() adds a canonicalising v_max per operand) */
@@ -465,7 +483,8 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
     tc_query q;
     query_setup(k, xi, yi, zi, h, q);
     const uint32_t *cum = k.cum + q.off;
-    const float4 *mirror = vgpr_ptr(k.mirror);
+    const tc_gpos mirror = vgpr_pos(k.mirror);
+    const uint32_t padslot = vgpr_u32(k.mirror_pad);
     const int nrow = q.nd[0] * q.nd[1];
     uint32_t ncand = 0;
     for (int rbase = 0; rbase < nrow; rbase += 64) {
@@ -503,10 +522,10 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
                 const uint32_t sc = hsum[u] + carry;
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)hsum[u], 63);
                 const uint32_t m = base + 64 * u + lane;
-                j[u] = m < total ? m + sc : k.mirror_pad;       /* padding lanes: the slot at infinity */
+                j[u] = m < total ? m + sc : padslot;            /* padding lanes: the slot at infinity */
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = mirror[j[u]];
+            for (int u = 0; u < 4; u++) p[u] = ld4(mirror, j[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (base + 64 * u < total) {
@@ -1145,7 +1164,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         /* the gather below is compiled twice (tag F): on the row-run path nothing wraps, positions come
          * from the mirror and "self" is the slot whose Peano index is i -- all compile-time there */
 
-        const float4 *vmirror = vgpr_ptr(k.mirror);
+        const tc_gpos vmirror = vgpr_pos(k.mirror);
         tc_list2 L;
         L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
         L.out.lds = lds_lists + TC_ICAP; L.out.spill = spill + TC_NGBMAX;  L.out.cap = TC_OCAP;
@@ -1159,7 +1178,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
             const bool valid = lane < nvalid;
-            const float4 pj = F ? vmirror[valid ? dj[sl] : 0u] : k.pos4[valid ? dj[sl] : (uint32_t)i];
+            const float4 pj = F ? ld4(vmirror, valid ? dj[sl] : 0u) : k.pos4[valid ? dj[sl] : (uint32_t)i];
             const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
             const bool inn = valid && (r2 < h0sq);
             const bool outr = valid && !inn;
@@ -1184,7 +1203,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             const bool wr = F ? false : wrap;
             wave_lds_fence();
             int sl = (whead + lane) & (TC_STAGE - 1);
-            const float4 p = F ? vmirror[lane < nvalid ? wj[sl] : 0u] : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
+            const float4 p = F ? ld4(vmirror, lane < nvalid ? wj[sl] : 0u) : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
             if (lane < nvalid && TC_ABLATE(k) != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wr);
             whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
