@@ -25,6 +25,7 @@
  */
 #include <type_traits>
 #include "tc_ctx.h"
+#include "tc_lean.h"
 
 /* Stage ablation for instruction-count profiling (tools/ablate_iter.py) is compiled in only with
  * -DTC_PROFILE_ABLATE (make ablate -> ../lib/libtcgpu_ablate.so); the product kernels carry no such branches. */
@@ -310,7 +311,9 @@ __device__ __forceinline__ double pair_r_w(float xi, float yi, float zi, float x
         if (dz > boxhalf) dz -= boxsize;
         if (dz < -boxhalf) dz += boxsize;
     }
-    return sqrt(dx * dx + dy * dy + dz * dz);
+    /* a sum of squares of f32 differences is 0 or >= 1e-90: far above the 2^-767 where the IEEE root starts
+     * to rescale, so the unscaled core returns the same bits (tc_lean.h) */
+    return tc_sqrt_f64_lean(dx * dx + dy * dy + dz * dz);
 }
 
 /* cell edge the query of radius h will use */
@@ -957,16 +960,28 @@ __device__ __forceinline__ void wvt_pair(const float4 pi, const float4 pj, doubl
     float r2 = (dx * dx + dy * dy + dz * dz);
     float h = (float)(0.5 * (double)(pi.w + pj.w));
     if (r2 > h * h) return;
-    /* (float)sqrt((double)r2) == sqrtf(r2): both are the correctly rounded f32 root */
-    float r = sqrtf(r2);
+    /* (float)sqrt((double)r2) == sqrtf(r2): both are the correctly rounded f32 root.  Root, quotient and
+     * reciprocal without the IEEE range handling where no operand needs it (tc_lean.h: same bits); the
+     * branch is uniform over the lanes that got here */
+    float r, q;
+    double rinv;
+    if (tc_ballot(r2 < 1e-24f && r2 > 0.0f)) {
+        r = sqrtf(r2);
+        q = r / h;
+        rinv = 1.0 / (double)r;
+    } else {
+        r = tc_sqrt_f32_lean(r2);
+        q = tc_div_f32_lean(r, h);
+        rinv = tc_rcp_f64_lean((double)r);
+    }
     /* src/wvt_relax.c:275-281 with t^8 by squaring and a Horner/FMA polynomial (terms move by a few
      * ulp of f64 before wk is rounded to f32, as in solve_hsml) */
-    const double u = (double)(r / h);
+    const double u = (double)q;
     const double t = 1 - u;
     const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
     float wk = (float)(TC_WC6_NORM * t8 * fma(u, fma(u, fma(u, 32.0, 25.0), 8.0), 1.0));
     /* step*hsml_i*wk*d/r for the three components with one reciprocal of r */
-    double base = step_hi * (double)wk * (1.0 / (double)r);
+    double base = step_hi * (double)wk * rinv;
     d0 = fma(base, (double)dx, d0);
     d1 = fma(base, (double)dy, d1);
     d2 = fma(base, (double)dz, d2);
