@@ -20,7 +20,7 @@ __device__ double logu(uint64_t &s, double lo, double hi) { return exp(log(lo) +
 __global__ void check(unsigned long long *bad, int per_thread)
 {
     uint64_t s = 0x1234567ull + (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 7919;
-    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
     for (int i = 0; i < per_thread; i++) {
         // f64 sqrt of a sum of squares of kpc-scale separations
         double x = logu(s, 1e-8, 1e10);
@@ -36,8 +36,11 @@ __global__ void check(unsigned long long *bad, int per_thread)
         // f64 reciprocal of an f32 distance
         double rd = (double)r;
         if (rd > 0 && __builtin_bit_cast(uint64_t, tc_rcp_f64_lean(rd)) != __builtin_bit_cast(uint64_t, 1.0 / rd)) b3++;
+        // f64 quotient of two numbers anywhere in 1e-60 .. 1e60, either sign
+        double a = logu(s, 1e-60, 1e60) * (u01(s) < 0.5 ? -1 : 1), b = logu(s, 1e-60, 1e60) * (u01(s) < 0.5 ? -1 : 1);
+        if (__builtin_bit_cast(uint64_t, tc_div_f64_lean(a, b)) != __builtin_bit_cast(uint64_t, a / b)) b4++;
     }
-    atomicAdd(&bad[0], b0); atomicAdd(&bad[1], b1); atomicAdd(&bad[2], b2); atomicAdd(&bad[3], b3);
+    atomicAdd(&bad[0], b0); atomicAdd(&bad[1], b1); atomicAdd(&bad[2], b2); atomicAdd(&bad[3], b3); atomicAdd(&bad[4], b4);
 }
 
 __global__ void specials(double *o)
@@ -51,18 +54,18 @@ __global__ void specials(double *o)
 
 int main()
 {
-    unsigned long long *bad, h[4];
-    hipMalloc(&bad, 4 * sizeof(*bad));
-    hipMemset(bad, 0, 4 * sizeof(*bad));
+    unsigned long long *bad, h[5];
+    hipMalloc(&bad, 5 * sizeof(*bad));
+    hipMemset(bad, 0, 5 * sizeof(*bad));
     const int blocks = 4096, threads = 256, per = 256;
     check<<<blocks, threads>>>(bad, per);
     hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost);
     printf("samples per function: %.3g\n", (double)blocks * threads * per);
-    printf("mismatches: sqrt_f64 %llu  sqrt_f32 %llu  div_f32 %llu  rcp_f64 %llu\n", h[0], h[1], h[2], h[3]);
+    printf("mismatches: sqrt_f64 %llu  sqrt_f32 %llu  div_f32 %llu  rcp_f64 %llu  div_f64 %llu\n", h[0], h[1], h[2], h[3], h[4]);
     double *o, ho[10];
     hipMalloc(&o, sizeof(ho));
     specials<<<1, 1>>>(o);
     hipMemcpy(ho, o, sizeof(ho), hipMemcpyDeviceToHost);
     for (int i = 0; i < 10; i += 2) printf("special %d: lean %g  ieee %g\n", i / 2, ho[i], ho[i + 1]);
-    return (h[0] | h[1] | h[2] | h[3]) ? 1 : 0;
+    return (h[0] | h[1] | h[2] | h[3] | h[4]) ? 1 : 0;
 }

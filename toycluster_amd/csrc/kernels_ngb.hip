@@ -655,10 +655,11 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         pairs += cnt;
 
         const float hf = (float)hsml;
-        const double norm_h3 = TC_WC6_NORM / (double)(hf * hf * hf);
-        const double norm_h4 = TC_WC6_NORM / (double)(hf * hf * hf * hf) * -22.0;
+        /* positive operands far from the exponent limits: the unscaled divide returns the IEEE bits (tc_lean.h) */
+        const double norm_h3 = tc_div_f64_lean(TC_WC6_NORM, (double)(hf * hf * hf));
+        const double norm_h4 = tc_div_f64_lean(TC_WC6_NORM, (double)(hf * hf * hf * hf)) * -22.0;
         const double h3 = hsml * hsml * hsml;
-        const double inv_h = 1 / hsml;
+        const double inv_h = tc_div_f64_lean(1.0, hsml);
         const double three_h = 3 * inv_h;
         const double nmpart = -mpart;
         const double fpt_h3 = TC_FOURPITHIRD * h3;

@@ -60,4 +60,17 @@ __device__ __forceinline__ double tc_rcp_f64_lean(double b)
     return b == 0 ? 1.0 / b : q;
 }
 
+/* a / b for |a|, |b| well inside the normal range (no quotient near the exponent limits) */
+__device__ __forceinline__ double tc_div_f64_lean(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
 #endif
