@@ -157,6 +157,7 @@ int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
  *   "fuse" [1]        fused density + sweep kernel; 0 = one plain kernel per reference loop
  *   "rows" [1]        row-run candidate streaming over the row-major mirror (set before upload)
  *   "level_shift" [1] cell level finer than the smoothing length by this many octree levels
+ *   "level_scale" [2^(1/4)] the radius is multiplied by this before its level is chosen
  *   "lmax" [auto]     deepest cell-table level (set before upload)
  *   "force_comm" [0]  tests: run the RCCL calls with a 1-rank communicator
  *   "ablate" [0]      only honoured by the profiling build libtcgpu_ablate.so (results invalid) */

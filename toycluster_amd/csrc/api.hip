@@ -111,6 +111,7 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     c->fuse = 1;
     c->rows = 1;
     c->level_shift = 1;                          /* cells of h/4..h/2: fewest candidates per query (tools/fuse_stats.py) */
+    c->level_scale = 1.189207115002721;           /* 2^(1/4): cells of h/3.4..h/1.7, measured best (tools/shift_probe.py) */
     ok = ok && hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess;
     ok = ok && hipMemset(c->flags, 0, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMemset(c->norph, 0, sizeof(int)) == hipSuccess;
@@ -828,6 +829,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     if (!strcmp(name, "stats")) c->want_stats = value != 0;
     else if (!strcmp(name, "timing")) c->timing = value != 0;
     else if (!strcmp(name, "level_shift")) c->level_shift = (int)value;
+    else if (!strcmp(name, "level_scale")) c->level_scale = value > 0 ? value : 1.0;
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
     else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = 0; }

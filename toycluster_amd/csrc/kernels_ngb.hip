@@ -192,7 +192,7 @@ struct tc_query {
  * floor(log2(box/h)) from the exponents and mantissas of the two numbers (no division). */
 __device__ __forceinline__ int query_level(const tc_dev_const &k, float h)
 {
-    const double hd = (double)h;
+    const double hd = (double)h * k.level_scale;
     int L = 1;
     if (hd <= k.boxsize) {
         const int eh = __builtin_amdgcn_frexp_exp(hd) - 1;                 /* hd = mh * 2^eh, mh in [1, 2) */
@@ -877,6 +877,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->boxhalf_f = (float)(c->par.boxsize * 0.5);       /* src/tree.c:28 */
     k->lmax = c->lmax;
     k->level_shift = c->level_shift;
+    k->level_scale = c->level_scale;
     k->cells = c->cells;
     k->orphans = c->orphans;
     k->norph = c->norph;

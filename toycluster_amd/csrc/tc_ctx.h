@@ -34,6 +34,7 @@ struct tc_dev_const {
     float boxsize_f, boxhalf_f;
     int lmax;                     /* deepest table level in use */
     int level_shift;              /* added to floor(log2(box/h))+1 when choosing the query level */
+    double level_scale;           /* h is multiplied by this before the level is chosen (tuning) */
     const uint2 *cells;           /* {~first, last+1} per cell; level L at offset tc_level_offset(L) */
     const uint32_t *orphans;      /* particles with a coordinate == boxsize (X has bit 63) */
     const int *norph;
@@ -107,6 +108,7 @@ struct tcgpu_ctx {
     int mirror_valid;
     int rows;                     /* option: use the row-run fast path (default 1) */
     int level_shift;
+    double level_scale;
     int lmax_override;
     int ablate;
 
