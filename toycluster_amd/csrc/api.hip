@@ -105,6 +105,7 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipHostMalloc(&c->h_flags, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMalloc(&c->orphans, sizeof(uint32_t) * TC_MAX_ORPHANS) == hipSuccess;
     ok = ok && hipMalloc(&c->norph, sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->work_ctr, 8 * 16 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->ngb_cnt, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->spill, sizeof(double) * (size_t)TC_MAX_PERSISTENT_BLOCKS * TC_WAVES_PER_BLOCK
                                         * (2 * TC_NGBMAX)) == hipSuccess;
@@ -148,7 +149,7 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_particles(c);
     hipFree(c->d_halo); hipFree(c->red); hipHostFree(c->h_red); hipFree(c->flags); hipHostFree(c->h_flags);
-    hipFree(c->orphans); hipFree(c->norph); hipFree(c->ngb_cnt); hipFree(c->spill);
+    hipFree(c->orphans); hipFree(c->norph); hipFree(c->work_ctr); hipFree(c->ngb_cnt); hipFree(c->spill);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);

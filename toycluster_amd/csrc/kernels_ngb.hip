@@ -1112,6 +1112,7 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
 struct tc_iter_args {
     tc_density_args d;
     double *ustep;             /* 3n, unit-step displacement sums; NULL => density only */
+    int *work_ctr;             /* per XCD group (stride 16 ints): next unassigned particle of the group's range */
 };
 
 /* Sized for 4 waves per SIMD (<= 128 VGPRs, 4 blocks x 38.9 KB LDS per CU): measured 4 % faster than 3 waves
@@ -1120,7 +1121,17 @@ struct tc_iter_args {
 #define TC_OCAP 384            /* outer entries in LDS */
 #define TC_ITER_IDXCAP 256
 #define TC_ITER_MINWAVES 4
+#define TC_WORK_CHUNK 4         /* particles a wave takes from the queue at a time */
 #define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 4 * TC_STAGE * sizeof(float))
+
+#ifdef TC_PROFILE_ABLATE
+/* profiling build only: begin / end time (100 MHz counter) of every wave of the last k_iter launch */
+__device__ uint64_t g_wave_span[2 * TC_MAX_PERSISTENT_BLOCKS * WPB];
+extern "C" int tcgpu_debug_wave_spans(uint64_t *out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_span), sizeof(uint64_t) * 2 * (size_t)nwaves) == hipSuccess ? 0 : -1;
+}
+#endif
 
 /* STATS: keep the per-particle work counters (queries, solver iterations, pair evaluations, candidates) that
  * tcgpu_last_density_stats reports; without them the counters are dead code and cost no scalar registers */
@@ -1331,8 +1342,42 @@ __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
     unsigned char *mine = lds_raw + (size_t)wave * TC_LDS_PER_WAVE_ITER;
     const int gw = blockIdx.x * WPB + wave;
     double *spill = a.d.spill + (size_t)gw * (2 * TC_NGBMAX);
-    const tc_stride ws = wave_stride(a.d.k.lo, a.d.k.hi, wave);
-    for (int i = ws.first; i < ws.end; i += ws.step) iter_one<STATS, WVT>(a, i, mine, spill);
+#ifdef TC_PROFILE_ABLATE
+    const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    /* Dynamic work queue.  The instruction arbiter favours the oldest wave of a SIMD, so with a static
+     * assignment the four waves of a SIMD finish one after the other (the first at 56 % of the launch time,
+     * measured) and the SIMD spends the last 40 % of the launch under-occupied.  Here every wave keeps pulling
+     * small chunks of particles until the pool is empty, so all waves end within one chunk of each other.
+     * Locality as before: blocks with equal blockIdx % 8 (one XCD under round-robin dealing) drain their own
+     * contiguous eighth of the Peano range first, then help the other eighths.  Which wave solves which
+     * particle never affects results. */
+    const int lo = a.d.k.lo, hi = a.d.k.hi;
+    const bool grouped = gridDim.x >= 16 && (gridDim.x & 7) == 0;
+    const int ngroups = grouped ? 8 : 1;
+    const int glen = grouped ? ((hi - lo + 7) >> 3) : (hi - lo);
+    const int g0 = grouped ? (int)(blockIdx.x & 7) : 0;
+    for (int gg = 0; gg < ngroups; gg++) {
+        const int grp = (g0 + gg) & (ngroups - 1);
+        const int gstart = lo + grp * glen;
+        int gend = gstart + glen;
+        if (gend > hi) gend = hi;
+        for (;;) {
+            uint32_t got = 0;                       /* unsigned: the counter keeps growing after the range is empty */
+            if ((threadIdx.x & 63) == 0) got = atomicAdd(reinterpret_cast<unsigned int *>(&a.work_ctr[16 * grp]), (unsigned int)TC_WORK_CHUNK);
+            got = U(got);
+            if (got >= (uint32_t)(gend - gstart)) break;
+            const int base = gstart + (int)got;
+            const int stop = base + TC_WORK_CHUNK < gend ? base + TC_WORK_CHUNK : gend;
+            for (int i = base; i < stop; i++) iter_one<STATS, WVT>(a, i, mine, spill);
+        }
+    }
+#ifdef TC_PROFILE_ABLATE
+    if ((threadIdx.x & 63) == 0 && gw < TC_MAX_PERSISTENT_BLOCKS * WPB) {       /* profiling build: wave life span */
+        g_wave_span[2 * gw] = t_begin;
+        g_wave_span[2 * gw + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
@@ -1350,6 +1395,8 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     a.d.stats = c->want_stats ? c->stats : nullptr;
     a.d.stats_stride = (int)c->cap;
     a.ustep = with_wvt ? c->ustep : nullptr;
+    a.work_ctr = c->work_ctr;
+    TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     int nloc = a.d.k.hi - a.d.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_DENSITY);

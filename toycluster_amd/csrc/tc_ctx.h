@@ -98,6 +98,7 @@ struct tcgpu_ctx {
     int num_cu;
     uint32_t *orphans;
     int *norph;
+    int *work_ctr;                /* 8 x 16 ints: per-XCD-group particle counters of the dynamic work queue */
     int index_valid;
     uint32_t *cum;                /* ncells(lmax_rm)+1 */
     float4 *mirror;               /* lmax_rm x cap */
