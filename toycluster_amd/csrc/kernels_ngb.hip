@@ -541,29 +541,44 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
     return ncand;
 }
 
-/* Persistent-grid work assignment, XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs
- * (blockIdx % 8 names the group that shares an L2), so each group of blocks strides over its own
- * contiguous eighth of the Peano range: the candidates one L2 has to hold are then one compact
- * region of space instead of an eighth of everything.  Placement only affects speed, never results. */
-struct tc_stride { int first, end, step; };
+/* Persistent-grid work assignment: a dynamic queue, XCD-aware.
+ *
+ * The instruction arbiter favours the oldest wave of a SIMD, so with a static assignment the four waves of a
+ * SIMD finish one after the other (the first at 56 % of the launch time, measured) and the SIMD spends the last
+ * 40 % of the launch under-occupied.  Here every wave keeps pulling small chunks of particles until the pool is
+ * empty, so all waves end within one chunk of each other (k_iter: -19 %).
+ * Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the group that shares an L2); each
+ * group drains its own contiguous eighth of the Peano range first -- the candidates one L2 has to hold are then
+ * one compact region of space instead of an eighth of everything -- and then helps the other eighths.
+ * Which wave solves which particle affects speed only, never results.  The launcher zeroes the counters. */
+#define TC_WORK_CHUNK 4         /* particles a wave takes from the queue at a time */
 
-__device__ __forceinline__ tc_stride wave_stride(int lo, int hi, int wave)
+template <class F>
+__device__ __forceinline__ void work_queue(const tc_dev_const &k, F &&f)
 {
-    tc_stride s;
-    const int nblk = (int)gridDim.x, b = (int)blockIdx.x;
-    if (nblk < 16 || (nblk & 7)) {                  /* tiny grids: plain striding */
-        s.first = lo + b * WPB + wave; s.end = hi; s.step = nblk * WPB;
-        return s;
+    const int lo = k.lo, hi = k.hi;
+    const bool grouped = gridDim.x >= 16 && (gridDim.x & 7) == 0;
+    const int ngroups = grouped ? 8 : 1;
+    const int glen = grouped ? ((hi - lo + 7) >> 3) : (hi - lo);
+    const int g0 = grouped ? (int)(blockIdx.x & 7) : 0;
+    for (int gg = 0; gg < ngroups; gg++) {
+        const int grp = (g0 + gg) & (ngroups - 1);
+        const int gstart = lo + grp * glen;
+        int gend = gstart + glen;
+        if (gend > hi) gend = hi;
+        if (gend <= gstart) continue;
+        for (;;) {
+            uint32_t got = 0;                       /* unsigned: the counter keeps growing after the range is empty */
+            if ((threadIdx.x & 63) == 0)
+                got = atomicAdd(reinterpret_cast<unsigned int *>(&k.work_ctr[16 * grp]), (unsigned int)TC_WORK_CHUNK);
+            got = U(got);
+            if (got >= (uint32_t)(gend - gstart)) break;
+            const int base = gstart + (int)got;
+            const int stop = base + TC_WORK_CHUNK < gend ? base + TC_WORK_CHUNK : gend;
+            for (int i = base; i < stop; i++) f(i);
+        }
     }
-    const int g = b & 7, bl = b >> 3, per = nblk >> 3;
-    const int len = (hi - lo + 7) >> 3;
-    int start = lo + g * len, end = start + len;
-    if (end > hi) end = hi;
-    s.first = start + bl * WPB + wave; s.end = end; s.step = per * WPB;
-    return s;
 }
-
-/* ------------------------------------------------------------------ K5 density */
 
 struct tc_density_args {
     tc_dev_const k;
@@ -860,8 +875,7 @@ __global__ __launch_bounds__(TBN) void k_density(tc_density_args a)
     st.y = st.x + TC_STAGE;
     st.z = st.y + TC_STAGE;
     st.w = nullptr;
-    const tc_stride ws = wave_stride(a.k.lo, a.k.hi, wave);
-    for (int i = ws.first; i < ws.end; i += ws.step) density_one(a, i, rl, idx, st);
+    work_queue(a.k, [&](int i) { density_one(a, i, rl, idx, st); });
 }
 
 void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
@@ -894,6 +908,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     if (lo > hi) lo = hi;
     k->lo = (int)lo;
     k->hi = (int)hi;
+    k->work_ctr = c->work_ctr;
     k->ablate = c->ablate;
 }
 
@@ -929,6 +944,7 @@ int tc_launch_density(tcgpu_ctx *c)
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_DENSITY);
+    TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     k_density<<<grid_for(c, nloc, k_density), TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
@@ -1075,8 +1091,7 @@ __global__ __launch_bounds__(TBN) void k_wvt(tc_wvt_args a)
     st.y = st.x + TC_STAGE;
     st.z = st.y + TC_STAGE;
     st.w = st.z + TC_STAGE;
-    const tc_stride ws = wave_stride(a.k.lo, a.k.hi, wave);
-    for (int i = ws.first; i < ws.end; i += ws.step) wvt_one(a, i, idx, st);
+    work_queue(a.k, [&](int i) { wvt_one(a, i, idx, st); });
 }
 
 int tc_launch_wvt(tcgpu_ctx *c, double step)
@@ -1089,6 +1104,7 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_WVT);
+    TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     k_wvt<<<grid_for(c, nloc, k_wvt), TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
@@ -1112,7 +1128,6 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
 struct tc_iter_args {
     tc_density_args d;
     double *ustep;             /* 3n, unit-step displacement sums; NULL => density only */
-    int *work_ctr;             /* per XCD group (stride 16 ints): next unassigned particle of the group's range */
 };
 
 /* Sized for 4 waves per SIMD (<= 128 VGPRs, 4 blocks x 38.9 KB LDS per CU): measured 4 % faster than 3 waves
@@ -1121,7 +1136,6 @@ struct tc_iter_args {
 #define TC_OCAP 384            /* outer entries in LDS */
 #define TC_ITER_IDXCAP 256
 #define TC_ITER_MINWAVES 4
-#define TC_WORK_CHUNK 4         /* particles a wave takes from the queue at a time */
 #define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 4 * TC_STAGE * sizeof(float))
 
 #ifdef TC_PROFILE_ABLATE
@@ -1345,33 +1359,7 @@ __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
 #ifdef TC_PROFILE_ABLATE
     const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-    /* Dynamic work queue.  The instruction arbiter favours the oldest wave of a SIMD, so with a static
-     * assignment the four waves of a SIMD finish one after the other (the first at 56 % of the launch time,
-     * measured) and the SIMD spends the last 40 % of the launch under-occupied.  Here every wave keeps pulling
-     * small chunks of particles until the pool is empty, so all waves end within one chunk of each other.
-     * Locality as before: blocks with equal blockIdx % 8 (one XCD under round-robin dealing) drain their own
-     * contiguous eighth of the Peano range first, then help the other eighths.  Which wave solves which
-     * particle never affects results. */
-    const int lo = a.d.k.lo, hi = a.d.k.hi;
-    const bool grouped = gridDim.x >= 16 && (gridDim.x & 7) == 0;
-    const int ngroups = grouped ? 8 : 1;
-    const int glen = grouped ? ((hi - lo + 7) >> 3) : (hi - lo);
-    const int g0 = grouped ? (int)(blockIdx.x & 7) : 0;
-    for (int gg = 0; gg < ngroups; gg++) {
-        const int grp = (g0 + gg) & (ngroups - 1);
-        const int gstart = lo + grp * glen;
-        int gend = gstart + glen;
-        if (gend > hi) gend = hi;
-        for (;;) {
-            uint32_t got = 0;                       /* unsigned: the counter keeps growing after the range is empty */
-            if ((threadIdx.x & 63) == 0) got = atomicAdd(reinterpret_cast<unsigned int *>(&a.work_ctr[16 * grp]), (unsigned int)TC_WORK_CHUNK);
-            got = U(got);
-            if (got >= (uint32_t)(gend - gstart)) break;
-            const int base = gstart + (int)got;
-            const int stop = base + TC_WORK_CHUNK < gend ? base + TC_WORK_CHUNK : gend;
-            for (int i = base; i < stop; i++) iter_one<STATS, WVT>(a, i, mine, spill);
-        }
-    }
+    work_queue(a.d.k, [&](int i) { iter_one<STATS, WVT>(a, i, mine, spill); });
 #ifdef TC_PROFILE_ABLATE
     if ((threadIdx.x & 63) == 0 && gw < TC_MAX_PERSISTENT_BLOCKS * WPB) {       /* profiling build: wave life span */
         g_wave_span[2 * gw] = t_begin;
@@ -1395,7 +1383,6 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     a.d.stats = c->want_stats ? c->stats : nullptr;
     a.d.stats_stride = (int)c->cap;
     a.ustep = with_wvt ? c->ustep : nullptr;
-    a.work_ctr = c->work_ctr;
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     int nloc = a.d.k.hi - a.d.k.lo;
     if (nloc <= 0) return 0;
@@ -1492,8 +1479,7 @@ __global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
     __shared__ __align__(16) uint32_t lds_idx[WPB * TC_IDXCAP];
     const int wave = threadIdx.x >> 6;
     uint32_t *idx = lds_idx + (size_t)wave * TC_IDXCAP;
-    const tc_stride ws = wave_stride(a.k.lo, a.k.hi, wave);
-    for (int i = ws.first; i < ws.end; i += ws.step) curl_one(a, i, idx);
+    work_queue(a.k, [&](int i) { curl_one(a, i, idx); });
 }
 
 int tc_launch_curl(tcgpu_ctx *c)
@@ -1508,6 +1494,7 @@ int tc_launch_curl(tcgpu_ctx *c)
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_CURL);
+    TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     k_curl<<<grid_for(c, nloc, k_curl), TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());

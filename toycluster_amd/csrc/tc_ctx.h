@@ -49,6 +49,7 @@ struct tc_dev_const {
     uint32_t mirror_pad;          /* slot holding a position at infinity (padding lanes load it) */
     int n;                        /* all particles (neighbour candidates) */
     int lo, hi;                   /* [lo,hi): the particles this GPU solves for */
+    int *work_ctr;                /* dynamic work queue: per XCD group (stride 16 ints) the next unassigned particle */
     int ablate;                   /* profiling only: 1 producer only, 2 +predicate, 3 no solver (results invalid) */
 };
 
