@@ -1265,16 +1265,20 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             if (dcnt >= 64) { convert_d(ftag, 64); dcnt = U(dcnt - 64); }
             if (do_wvt) {
                 const bool hwv = act && (r2 < hwsq);
-                cw = U(cw + (int)__popcll(tc_ballot(hwv)));
+                uint64_t mw = tc_ballot(hwv);
+                cw = U(cw + (int)__popcll(mw));
+                /* the particle itself (the only hit at distance zero, bar coincident particles) is not a sweep
+                 * neighbour: found once per particle, so the test sits behind a wave-uniform branch */
+                uint32_t wslot = (uint32_t)mask_rank(mw);
                 bool use = hwv;
-                if (F) {                                      /* the particle itself: the slot whose Peano index is i */
-                    if (use && r2 == 0.0f) use = k.mirror_idx[j] != (uint32_t)i;
-                } else {
-                    use = hwv && j != (uint32_t)i;
+                if (tc_ballot(hwv && r2 == 0.0f)) {
+                    const bool self = hwv && r2 == 0.0f && (F ? k.mirror_idx[j] == (uint32_t)i : j == (uint32_t)i);
+                    use = hwv && !self;
+                    mw = tc_ballot(use);
+                    wslot = (uint32_t)mask_rank(mw);
                 }
-                const uint64_t mw = tc_ballot(use);
                 if (use) {
-                    int sl = (whead + wcnt + mask_rank(mw)) & (TC_STAGE - 1);
+                    int sl = (whead + wcnt + (int)wslot) & (TC_STAGE - 1);
                     wj[sl] = (uint32_t)j;
                 }
                 wcnt = U(wcnt + (int)__popcll(mw));
