@@ -89,6 +89,36 @@ def test_sort_with_duplicates_and_box_faces(gpu):
             assert np.array_equal(a, b), (i, h, len(a), len(b))
 
 
+def test_sort_large_set_with_close_pairs():
+    """Above 2^20 particles the radix sort looks at fewer leading key bits and the fix-up orders what ties
+    (csrc/sort.hip).  Half a million close pairs (offsets of 1e-6 .. 1e-4 of the box: equal in the sorted bits,
+    different below) must still come out in full 128-bit key order, ids carried along."""
+    n = 1_300_000
+    m = M.preset("single", n)
+    rng = np.random.default_rng(17)
+    box = np.float32(m.boxsize)
+    pos = (rng.random((n, 3)) * 0.98 + 0.01).astype(np.float32) * box
+    k = 500_000
+    pos[n - k:] = pos[:k] + (rng.random((k, 3)) * 1e-4 + 1e-6).astype(np.float32) * box
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    g = binding.TcGpu(0)
+    g.set_model(m)
+    g.upload(pos, ids)
+    hi, lo = g.Sort_Particles_By_Peano_Key()
+    p = g.particles()
+    g.close()
+    assert np.all(hi[1:] >= hi[:-1])
+    same = hi[1:] == hi[:-1]
+    assert np.all(lo[1:][same] >= lo[:-1][same])
+    assert np.array_equal(np.sort(p["id"]), ids)
+    assert np.array_equal(p["pos"], pos[p["id"] - 1])                  # whole particles moved
+    # keys belong to the particles they sit next to
+    for i in rng.integers(0, n, 50):
+        x, y, z = (float(v) / float(box) for v in p["pos"][i].astype(np.float64))
+        key = O.peano_key(x, y, z)
+        assert (key >> 64, key & ((1 << 64) - 1)) == (int(hi[i]), int(lo[i]))
+
+
 def test_sort_keys_tying_in_the_high_half(gpu):
     """Particles a few f32 ulps apart share the high 64 key bits (21 Hilbert levels) and differ only in the
     low half: the one-pass radix sort + tie fix-up must still give the full 128-bit order.  Includes a run

@@ -496,8 +496,12 @@ extern "C" int tcgpu_sort_particles_by_peano_key(tcgpu_ctx *c)
     int rc;
     if ((rc = tc_launch_keys(c))) return rc;
     tc_phase_begin(c, PH_SORT);
+    /* large sets: radix passes only over the Hilbert levels that separate particles in practice, five below
+     * the deepest cell-table level (3 bits per level); the fix-up orders whatever still ties, exactly */
+    int sort_levels = c->lmax + 5;
+    if (sort_levels > 21) sort_levels = 21;
     int s = tc_sort_pairs_u128(c->sort_tmp, c->sort_tmp_bytes, c->key, c->key_sorted, c->idx, c->idx_sorted,
-                               (size_t)c->n, c->stream);
+                               (size_t)c->n, 3 * sort_levels + 1, c->stream);
     tc_phase_end(c);
     if (s) TC_FAIL(c, TCGPU_ERR_HIP, "radix sort failed");
     if ((rc = tc_launch_permute(c))) return rc;

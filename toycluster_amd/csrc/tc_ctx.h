@@ -162,7 +162,7 @@ struct tcgpu_ctx {
 /* ---- launchers implemented in the kernel translation units ---- */
 int tc_sort_temp_bytes(size_t n, size_t *bytes);
 int tc_sort_pairs_u128(void *tmp, size_t tmp_bytes, const tc_u128 *kin, tc_u128 *kout,
-                       const uint32_t *vin, uint32_t *vout, size_t n, hipStream_t s);
+                       const uint32_t *vin, uint32_t *vout, size_t n, int sort_bits, hipStream_t s);
 
 int tc_launch_keys(tcgpu_ctx *c);
 int tc_launch_keys_xyz(tcgpu_ctx *c, int64_t n, const double *d_xyz, uint64_t *d_hi, uint64_t *d_lo);
