@@ -602,6 +602,42 @@ def test_particles_on_the_box_faces(gpu):
     assert len(log) == 3 and all(np.isfinite(l["err_mean"]) for l in log) and log[2]["err_mean"] < log[0]["err_mean"]
 
 
+def test_plain_kernels_match_oracle():
+    """Option "fuse" = 0: one plain kernel per reference loop (k_density for sph.c:19-72, k_wvt for
+    wvt_relax.c:126-171) instead of the fused kernel -- same results, same control flow."""
+    n = 20000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=41)
+    g = binding.TcGpu(0)
+    g.set_option("fuse", 0)
+    g.set_option("stats", 1)
+    g.set_model(m)
+    g.upload(pos, ids)
+    o = O.Oracle(m, pos, ids)
+    for _ in range(2):                                       # cold pass, then warm pass
+        g.Find_sph_quantities()
+        o.find_sph_quantities()
+        p, q = g.particles(), o.particles()
+        a, b = g.density_stats(), o.last_stats()
+        assert np.array_equal(p["id"], q["id"])
+        assert rel(p["hsml"], q["hsml"]).max() < 1e-6 and rel(p["rho"], q["rho"]).max() < 1e-6
+        assert a["queries"] == pytest.approx(b["queries"], rel=1e-3)
+        assert a["solver_iters"] == pytest.approx(b["solver_iters"], rel=1e-3)
+    log = g.Regularise_sph_particles(max_iter=3)
+    olog = o.regularise(max_iter=3)
+    g.Find_sph_quantities()
+    o.find_sph_quantities()
+    assert len(log) == len(olog)
+    for x, y in zip(log, olog):
+        assert x["it"] == y["it"] and x["step"] == y["step"]
+        assert x["err_mean"] == pytest.approx(y["err_mean"], rel=1e-5)
+    p, q = g.particles(), o.particles()
+    g.close()
+    assert np.array_equal(p["id"], q["id"])
+    assert (np.abs(p["pos"] - q["pos"]).max(axis=1) / q["hsml"]).max() < TOL_POS
+    assert rel(p["hsml"], q["hsml"]).max() < TOL_HSML and rel(p["rho"], q["rho"]).max() < TOL_RHO
+
+
 def test_row_run_path_matches_cell_path():
     """The fused kernel has two candidate producers: cell by cell over the Peano-ordered table (any ball) and
     run by run over the row-major mirror (interior balls at a mirrored level, the default where it applies).
