@@ -244,6 +244,9 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
     if ((double)lmax_rm * (double)(c->cap + 1) >= 4.0e9) lmax_rm = 0; /* slots are 32-bit */
     if (!c->rows) lmax_rm = 0;
     c->lmax_rm = lmax_rm;
+    /* the coarsest levels are queried by next to no particle (balls wider than 1/16 of the box): not worth a
+     * copy of every particle per level; those few queries take the cell-by-cell path */
+    c->lmin_rm = lmax_rm > 5 ? lmax_rm - 4 : 1;
     c->mirror_valid = 0;
     if (lmax_rm > 0) {
         size_t ncum = tc_level_offset(lmax_rm + 1) + 1, nslot = (size_t)lmax_rm * (size_t)c->cap;

@@ -901,6 +901,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->mirror = rm ? c->mirror : nullptr;
     k->mirror_idx = rm ? c->mirror_idx : nullptr;
     k->lmax_rm = rm ? c->lmax_rm : 0;
+    k->lmin_rm = rm ? c->lmin_rm : 1;
     k->mirror_pad = (uint32_t)c->mirror_alloc;
     k->n = (int)c->n;
     int64_t lo = c->rank * c->shard_len, hi = (c->rank + 1) * c->shard_len;
@@ -1202,7 +1203,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         /* interior ball at a mirrored level: candidates come as contiguous runs of the row-major mirror
          * (stream_rows); `j` is then a mirror slot.  No orphan (coordinate == boxsize) can be within R of an
          * interior particle, so skipping them there changes nothing. */
-        const bool fast = U((int)(!wrap && k.mirror != nullptr && qL <= k.lmax_rm)) != 0;
+        const bool fast = U((int)(!wrap && k.mirror != nullptr && qL <= k.lmax_rm && qL >= k.lmin_rm)) != 0;
         /* the gather below is compiled twice (tag F): on the row-run path nothing wraps, positions come
          * from the mirror and "self" is the slot whose Peano index is i -- all compile-time there */
 

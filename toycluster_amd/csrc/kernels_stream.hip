@@ -209,7 +209,7 @@ int tc_scan_temp_bytes(size_t ncell, size_t *bytes)
     return e == hipSuccess ? 0 : -1;
 }
 
-__global__ __launch_bounds__(TB) void k_mirror(const float4 *__restrict__ pos4, int n, double box, int lmax, int lmax_rm,
+__global__ __launch_bounds__(TB) void k_mirror(const float4 *__restrict__ pos4, int n, double box, int lmax, int lmin_rm, int lmax_rm,
                                                const uint2 *__restrict__ cells, const uint32_t *__restrict__ cum,
                                                float4 *__restrict__ mirror, uint32_t *__restrict__ mirror_idx)
 {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(TB) void k_mirror(const float4 *__restrict__ pos4, 
     bool orphan;
     cell_coords(p, box, lmax, ci, &orphan);
     if (orphan) return;                                   /* not in the table (see k_cells) */
-    for (int L = 1; L <= lmax_rm; L++) {
+    for (int L = lmin_rm; L <= lmax_rm; L++) {
         const int sh = lmax - L;
         const size_t nL = (size_t)1 << L;
         const size_t o = tc_level_offset(L) + (((size_t)(ci[0] >> sh) * nL) + (ci[1] >> sh)) * nL + (ci[2] >> sh);
@@ -241,7 +241,7 @@ int tc_launch_mirror(tcgpu_ctx *c)
     size_t b = c->scan_tmp_bytes;
     hipError_t e = rocprim::exclusive_scan(c->scan_tmp, b, in, c->cum, 0u, ncell, rocprim::plus<uint32_t>(), c->stream);
     if (e == hipSuccess)
-        k_mirror<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->lmax_rm,
+        k_mirror<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->lmin_rm, c->lmax_rm,
                                                          c->cells, c->cum, c->mirror, c->mirror_idx);
     tc_phase_end(c);
     TC_HIP(c, e);

@@ -45,7 +45,7 @@ struct tc_dev_const {
     const uint32_t *cum;          /* exclusive prefix sum of the cell populations over the whole table (+1 entry) */
     const float4 *mirror;         /* positions (w = hsml_wvt) in slot order */
     const uint32_t *mirror_idx;   /* slot -> Peano index */
-    int lmax_rm;
+    int lmax_rm, lmin_rm;         /* mirrored levels: lmin_rm..lmax_rm */
     uint32_t mirror_pad;          /* slot holding a position at infinity (padding lanes load it) */
     int n;                        /* all particles (neighbour candidates) */
     int lo, hi;                   /* [lo,hi): the particles this GPU solves for */
@@ -107,6 +107,7 @@ struct tcgpu_ctx {
     void *scan_tmp;
     size_t scan_tmp_bytes, cum_alloc, mirror_alloc;
     int lmax_rm;                  /* deepest mirrored level (0: none) */
+    int lmin_rm;                  /* coarsest mirrored level */
     int mirror_valid;
     int rows;                     /* option: use the row-run fast path (default 1) */
     int level_shift;
