@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Built artefacts are not part of the source tree: build whatever is missing (hipcc cross-compiles
+    without a GPU; everything else is gcc).  A no-op when __graft_entry__.build() has run already."""
+    need = [os.path.join(ROOT, "toycluster_amd", "lib", n) for n in ("libtcgpu.so", "libtchost.so", "libtcshim.so")]
+    need += [os.path.join(ROOT, "toycluster_amd", "host", "toycluster_hip"), os.path.join(ROOT, "oracle", "libtcoracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 class FixtureModel:
     """Model scalars as stored in a golden .npz (same attributes as toycluster_amd.model.ClusterModel)."""
 
