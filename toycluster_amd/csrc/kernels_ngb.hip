@@ -1016,55 +1016,51 @@ __device__ __forceinline__ void wvt_sum(const tc_dev_const &k, int i, const floa
     const float hq = (float)((double)pi.w * k.boxsize);      /* src/wvt_relax.c:135 */
     const float hq2 = hq * hq;
 
-    d0 = d1 = d2 = 0;
-    int cnt = 0, scnt = 0, head = 0;
-    /* hits are compacted into the LDS ring first so that the pair arithmetic runs on full waves */
-    auto convert = [&](int nvalid) {
-        wave_lds_fence();
-        int sl = (head + lane) & (TC_STAGE - 1);
-        float4 p = make_float4(st.x[sl], st.y[sl], st.z[sl], st.w[sl]);
-        if (lane < nvalid) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
-        head = U((head + 64) & (TC_STAGE - 1));
-        wave_lds_fence();
-    };
-    stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
-        float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
-        bool hit = act && (r2 < hq2);
-        cnt += __popcll(tc_ballot(hit));
-        bool use = hit && j != i;
-        uint64_t m = tc_ballot(use);
-        if (use) {
-            int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
-            st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = p.w;
-        }
-        scnt = U(scnt + (int)__popcll(m));
-        if (scnt >= 64) { convert(64); scnt = U(scnt - 64); }
-        return false;
-    });
-    if (scnt > 0) convert(scnt);
-
-    if (cnt >= TC_NGBMAX) {
-        /* The reference truncates the list to the first NGBMAX hits in ascending index
-         * (src/tree.c:91-92).  Find the index threshold T with exactly NGBMAX hits below it
-         * by bisection over re-gathers, then redo the sum with j < T.  Never seen in practice. */
-        if (lane == 0) atomicAdd(&flags[4], 1);
-        int tlo = 0, thi = k.n;                      /* count(j < tlo) < NGBMAX <= count(j < thi) */
-        while (thi - tlo > 1) {
-            int mid = tlo + ((thi - tlo) >> 1);
-            int cm = 0;
-            stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
-                float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
-                cm += __popcll(tc_ballot(act && (r2 < hq2) && j < mid));
-                return false;
-            });
-            if (cm >= TC_NGBMAX) thi = mid; else tlo = mid;
-        }
-        d0 = d1 = d2 = 0;
+    /* The reference truncates a list that overflows to its first NGBMAX hits in ascending index
+     * (src/tree.c:91-92) without noticing.  Reproduced by re-gathering: pass 0 sums over all hits and counts
+     * them; if there are NGBMAX or more, counting passes bisect the index threshold T with exactly NGBMAX hits
+     * below it and a last pass sums the hits with j < T.  One stream call site for all passes (code size). */
+    int limit = k.n, tlo = 0, thi = k.n, mode = 0;          /* 0: sum everything, 1: count j < limit, 2: sum j < limit */
+    for (;;) {
+        int cnt = 0, scnt = 0, head = 0;
+        if (mode != 1) d0 = d1 = d2 = 0;
+        /* hits are compacted into the LDS ring first so that the pair arithmetic runs on full waves */
+        auto convert = [&](int nvalid) {
+            wave_lds_fence();
+            int sl = (head + lane) & (TC_STAGE - 1);
+            float4 p = make_float4(st.x[sl], st.y[sl], st.z[sl], st.w[sl]);
+            if (lane < nvalid) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
+            head = U((head + 64) & (TC_STAGE - 1));
+            wave_lds_fence();
+        };
         stream_candidates(k, pi.x, pi.y, pi.z, hq, idx, idxcap, [&](int j, float4 p, bool act) -> bool {
             float r2 = tc_ngb_r2(pi.x, pi.y, pi.z, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
-            if (act && (r2 < hq2) && j < thi && j != i) wvt_pair(pi, p, boxinv, step_hi, d0, d1, d2);
+            bool hit = act && (r2 < hq2) && j < limit;
+            cnt += __popcll(tc_ballot(hit));
+            if (mode == 1) return false;
+            bool use = hit && j != i;
+            uint64_t m = tc_ballot(use);
+            if (use) {
+                int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
+                st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = p.w;
+            }
+            scnt = U(scnt + (int)__popcll(m));
+            if (scnt >= 64) { convert(64); scnt = U(scnt - 64); }
             return false;
         });
+        if (mode != 1 && scnt > 0) convert(scnt);
+        cnt = U(cnt);
+        if (mode == 0) {
+            if (cnt < TC_NGBMAX) break;
+            if (lane == 0) atomicAdd(&flags[4], 1);
+            mode = 1;                                        /* count(j < tlo) < NGBMAX <= count(j < thi) */
+        } else if (mode == 1) {
+            if (cnt >= TC_NGBMAX) thi = limit; else tlo = limit;
+        } else {
+            break;
+        }
+        if (thi - tlo > 1) limit = tlo + ((thi - tlo) >> 1);
+        else { mode = 2; limit = thi; }
     }
     d0 = wsum(d0); d1 = wsum(d1); d2 = wsum(d2);
 }
