@@ -29,6 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+F64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X vector f64 peak (half the 157.3 TF f32 vector peak of MI355X_MICROARCH.md)
+# SURVEY.md 8(d) flop model of one particle-iteration: every list entry the hsml solver visits costs ~60 flop
+# (f64 separation already paid, kernel + derivative polynomials, 1 sqrt, 1 f32 divide, ~2 f64 divides), the WVT
+# sweep ~350 pairs x ~40 flop = 14 kflop.  The number of solver visits is COUNTED by a stats pass of this run.
+FLOP_PER_SOLVER_PAIR = 60.0
+FLOP_SWEEP_PER_PARTICLE = 14.0e3
 BYTES_DENSITY_PER_PARTICLE = 56  # K5 (12+4 R, 12 W) + K9 (12+4 R, 12 W), fused in k_iter
 BYTES_ITER_PER_PARTICLE = 868    # whole iteration incl. 128-bit radix sort
 PER_GPU_PARTICLES = 2_000_000
@@ -53,6 +59,7 @@ def cpu_baseline(nsample, iters):
     o.regularise(max_iter=iters - 1)
     dt = time.time() - t0
     return {"value": nsample * iters / dt, "unit": "particle-iterations/s", "cores": cores, "kind": "port",
+            "sample_particles": nsample, "sample_iterations": iters, "sample_seconds": dt,
             "sample": "oracle/tc_oracle.c (OpenMP restatement of the reference path), 2-cluster merger, "
                       "%d particles, %d warm WVT iterations, %.1f s" % (nsample, iters, dt)}
 
@@ -64,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles-per-gpu", type=int, default=PER_GPU_PARTICLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-relax", action="store_true",
+                    help="profiling runs: skip the stats pass and the whole-relaxation run behind the timed steps")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--force-comm", action="store_true",
@@ -103,7 +112,6 @@ def main():
                       options={"force_comm": 1} if args.force_comm else None)
     g.set_model(m)
     g.upload(pos, ids)
-    del pos, ids
 
     step_size = 0.0085                                       # wvt_relax.c:51
 
@@ -138,19 +146,43 @@ def main():
     n_local = (n_total + world - 1) // world
     achieved = BYTES_DENSITY_PER_PARTICLE * n_local / dens_avg / 1e9 if dens_avg > 0 else 0.0
 
-    # HBM/fabric traffic of the dominant kernel: PMC counters cannot be collected from inside the
-    # process, so the figure measured by `tools/profile_round.sh` (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE passes of this same command) is read from profiles/ when present.
-    traffic = None
-    valu_insts = None
-    tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
-    if os.path.exists(tpath) and world == 1 and args.particles_per_gpu == PER_GPU_PARTICLES:
+    # Work counters of one density pass (stats instantiation of the same kernel, outside the timed region):
+    # list entries visited by the hsml solver per particle -> counted flops of the launch.
+    st = {"pair_evals": float("nan"), "queries": float("nan"), "candidates": float("nan")}
+    if not args.no_relax:
+        g.set_option("stats", 1)
+        g.density_error()
+        st = g.density_stats()
+        g.set_option("stats", 0)
+    flop_per_particle = st["pair_evals"] * FLOP_PER_SOLVER_PAIR + FLOP_SWEEP_PER_PARTICLE
+    tflops = flop_per_particle * n_local / dens_avg / 1e12 if dens_avg > 0 else 0.0
+
+    # One whole relaxation under the reference's stop rule (wvt_relax.c:94-98) from the same initial positions:
+    # the second half of BASELINE.json's metric ("iterations to <1% rho-error" = stop-rule count).
+    relax_log, relax_s = None, float("nan")
+    if not args.no_relax:
+        g.upload(pos, ids)
+        barrier()
+        t0 = time.perf_counter()
+        relax_log = g.Regularise_sph_particles()
+        barrier()
+        relax_s = time.perf_counter() - t0
+    del pos, ids
+
+    # Counter-derived figures of the dominant kernel cannot be collected from inside the process: they come from
+    # the rocprofv3 --pmc passes of tools/profile_round2.sh over this same command, summarised by
+    # tools/roofline_valu.py into profiles/dominant_kernel.json -- FILE values, labelled as such, and refused
+    # when the kernel sources have changed since the profile was taken.
+    prof = None
+    ppath = os.path.join(ROOT, "profiles", "dominant_kernel.json")
+    if os.path.exists(ppath) and world == 1 and args.particles_per_gpu == PER_GPU_PARTICLES:
         try:
-            tj = json.load(open(tpath))
-            traffic = tj["bytes_per_launch"]
-            valu_insts = tj.get("valu_insts_per_launch")
+            from tools import roofline_valu
+            pj = json.load(open(ppath))
+            if pj.get("kernel_sources_sha256") == roofline_valu.kernel_sources_sha256(ROOT):
+                prof = pj
         except Exception:
-            traffic = None
+            prof = None
 
     if rank == 0:
         cpu = None
@@ -158,7 +190,7 @@ def main():
             cpu = cpu_baseline(args.cpu_sample, args.cpu_iters)
         value = n_total * args.steps / dt
         out = {
-            "metric": "WVT-relaxed particles/sec (whole node)",
+            "metric": "WVT-relaxed particles/sec (whole node) + iterations to <1% rho-error",
             "value": value,
             "unit": "particle-iterations/s",
             "n_gpus": world,
@@ -174,14 +206,33 @@ def main():
                                    "WVT iterations (sort + density solve + sweep + move)" % args.particles_per_gpu,
                        "particles_total": n_total, "parallelism": "peano-range shards x%d, RCCL all-gather" % world,
                        "err_mean_last": errs[-1][0], "err_max_last": errs[-1][1]},
-            "roofline": {"bound": "hbm", "kernel": "k_iter (fused density solve K5 + WVT sweep K9)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # k_iter is a gather/stencil kernel bound by the vector ALU, not by HBM: the
+            # headline fraction is counted vector flops against the f64 vector peak; the HBM fraction of its
+            # compulsory 56 B/particle is reported beside it.
+            "roofline": {"bound": "valu", "kernel": "k_iter (fused density solve K5 + WVT sweep K9)",
+                         "achieved": tflops, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / F64_VECTOR_PEAK_TFLOPS,
+                         "flop_model": "counted solver list visits/particle (stats pass of this run) x %g flop + %g flop "
+                                       "for the sweep (SURVEY.md 8d), all counted as f64" % (FLOP_PER_SOLVER_PAIR, FLOP_SWEEP_PER_PARTICLE),
+                         "solver_pair_evals_per_particle": st["pair_evals"], "queries_per_particle": st["queries"],
+                         "candidates_per_particle": st["candidates"], "flop_per_particle": flop_per_particle,
                          "avg_launch_ms": 1e3 * dens_avg, "launches": dens_launch,
-                         "algorithmic_bytes_per_particle": BYTES_DENSITY_PER_PARTICLE,
-                         "whole_iteration_GBs": BYTES_ITER_PER_PARTICLE * n_total * args.steps / dt / 1e9 / world,
-                         # the kernel is VALU-bound, not HBM-bound: wave instructions of one
-                         # launch (rocprofv3 SQ_INSTS_VALU, profiles/) x 4 cycles / (1024 SIMDs x 2.4 GHz) / launch time
-                         "valu_issue_frac": (valu_insts * 4 / (1024 * 2.4e9) / dens_avg) if (valu_insts and dens_avg > 0) else None},
+                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_particle": BYTES_DENSITY_PER_PARTICLE,
+                                 "whole_iteration_GBs": BYTES_ITER_PER_PARTICLE * n_total * args.steps / dt / 1e9 / world},
+                         "traffic": prof["traffic_bytes_per_launch"] if prof else None,
+                         "profile": ({"source": "profiles/dominant_kernel.json (rocprofv3 --pmc passes, tools/profile_round2.sh); "
+                                                "file values from the profiling run, not measured by this run",
+                                      "commit": prof.get("commit"), "valu_insts_per_launch": prof.get("valu_insts_per_launch"),
+                                      "valu_insts_per_particle": prof.get("valu_insts_per_particle"),
+                                      "valu_issue_frac": prof.get("valu_issue_frac"),
+                                      "clock_ghz": prof.get("clock_ghz"), "l2_hit_rate": prof.get("l2_hit_rate")}
+                                     if prof else None)},
+            "relaxation": ({"iterations_to_stop": len(relax_log), "err_mean_at_stop": relax_log[-1]["err_mean"],
+                            "err_max_at_stop": relax_log[-1]["err_max"], "relax_wall_s": relax_s,
+                            "particles_per_s_to_convergence": n_total / relax_s,
+                            "stop_rule": "reference's own (wvt_relax.c:94-98); an absolute mean error < 1 % is not reached "
+                                         "by the reference either (SURVEY.md 6)"} if relax_log else None),
             "cpu_baseline": cpu,
             "phase_ms_per_step": {k: 1e3 * v[0] / args.steps for k, v in phases.items() if v[1]},
         }

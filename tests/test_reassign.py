@@ -100,3 +100,99 @@ def test_state_file_trailer_round_trip(tmp_path):
     open(path, "wb").write(raw)
     st = hostio.read_state_header(path)
     assert st["has_r_sample"] is True and st["r_sample"] == [h.r_sample for h in m.halos]
+
+
+# ---- the shim's Qsort_Index (src/sort.h:7-8; caller src/positions.c:409) and Peano_Key (src/peano.h:6) ----
+
+_SHIM = None
+
+
+def _shim():
+    """libtcshim.so expects the reference's globals (src/aux.c:3-13) from the program it is linked into; a
+    two-line C file compiled on the fly plays that program here."""
+    global _SHIM
+    if _SHIM is None:
+        import ctypes as C
+        import os
+        import subprocess
+        import tempfile
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        d = tempfile.mkdtemp(prefix="tcshim_")
+        src = os.path.join(d, "globals.c")
+        open(src, "w").write('#include "%s"\n'
+                             "struct Parameters Param; struct HaloProperties Halo[REF_MAXHALOS];\n"
+                             "struct ParticleData *P; struct GasParticleData *SphP;\n"
+                             % os.path.join(root, "toycluster_amd", "host", "tc_ref_abi.h"))
+        so = os.path.join(d, "libglobals.so")
+        subprocess.run(["gcc", "-std=c99", "-shared", "-fPIC", "-o", so, src], check=True)
+        C.CDLL(so, mode=C.RTLD_GLOBAL)
+        _SHIM = C.CDLL(os.path.join(root, "toycluster_amd", "lib", "libtcshim.so"))
+    return _SHIM
+
+
+@pytest.mark.parametrize("n,nkeys", [(1, 1), (2, 1), (9, 2), (1000, 3), (5000, 70)])
+def test_shim_qsort_index_with_the_reference_int_comparator(n, nkeys):
+    """Qsort_Index(nThreads, perm, data, nData, datasize, cmp) called the way sort_particles() does
+    (positions.c:391-397 compare_int on int halo ids): same permutation as the published heapsort, ties included,
+    and the same as the int-specialised host routine the executable uses."""
+    import ctypes as C
+    L = _shim()
+    CMP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+    def compare_int(a, b):
+        x = C.cast(a, C.POINTER(C.c_int))[0]
+        y = C.cast(b, C.POINTER(C.c_int))[0]
+        return (x > y) - (x < y)
+
+    rng = np.random.default_rng(n + nkeys)
+    keys = np.ascontiguousarray(rng.integers(0, nkeys, n), dtype=np.int32)
+    perm = np.full(n, 12345, dtype=np.uint64)                   # garbage in: the routine initialises it
+    L.Qsort_Index.restype = None
+    L.Qsort_Index.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, CMP]
+    L.Qsort_Index(8, perm.ctypes.data, keys.ctypes.data, n, 4, CMP(compare_int))
+    assert perm.tolist() == _python_heapsort_index(keys.tolist())
+    assert perm.tolist() == hostio.heapsort_index_i32(keys).tolist()
+
+
+def test_shim_qsort_index_on_128_bit_keys():
+    """The other data type the reference sorts with it: 16-byte Peano keys with compare_peanoKeys (peano.c:33-39)."""
+    import ctypes as C
+    L = _shim()
+    CMP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+    def compare_keys(a, b):
+        x = C.cast(a, C.POINTER(C.c_uint64))
+        y = C.cast(b, C.POINTER(C.c_uint64))
+        kx, ky = (x[1] << 64) | x[0], (y[1] << 64) | y[0]          # little endian u128
+        return (kx > ky) - (kx < ky)
+
+    rng = np.random.default_rng(3)
+    n = 777
+    keys = rng.integers(0, 2**63, (n, 2), dtype=np.uint64)
+    keys[100] = keys[5]                                             # one tie
+    perm = np.zeros(n, dtype=np.uint64)
+    L.Qsort_Index.restype = None
+    L.Qsort_Index.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, CMP]
+    L.Qsort_Index(1, perm.ctypes.data, keys.ctypes.data, n, 16, CMP(compare_keys))
+    big = [(int(k[1]) << 64) | int(k[0]) for k in keys]
+    assert perm.tolist() == _python_heapsort_index(big)
+
+
+def test_shim_peano_key_known_answers():
+    import ctypes as C
+    import json
+    import os
+    L = _shim()
+
+    class U128(C.Structure):
+        _fields_ = [("lo", C.c_uint64), ("hi", C.c_uint64)]
+
+    L.Peano_Key.restype = U128                                     # x86-64 SysV: __int128 comes back in rax:rdx
+    L.Peano_Key.argtypes = [C.c_double] * 3
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "peano_kat.json")))
+    assert len(kat["exact"]) == 11
+    for row in kat["exact"]:
+        x, y, z = row["xyz"]
+        want = int(row["key"], 16)
+        k = L.Peano_Key(x, y, z)
+        assert ((k.hi << 64) | k.lo) == want, (x, y, z)

@@ -261,6 +261,12 @@ class TcGpu:
         return b
 
     def phase_times(self, reset=False):
+        """Device seconds and launch counts per phase.  The library records HIP events per phase only with
+        option "timing" = 1 (off by default in the product path); the first call switches it on, so measure
+        between a phase_times(reset=True) and a phase_times()."""
+        if not getattr(self, "_timing_on", False):
+            self.set_option("timing", 1)
+            self._timing_on = True
         cap = 32
         names = (C.c_char_p * cap)()
         secs = (C.c_double * cap)()

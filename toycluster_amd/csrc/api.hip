@@ -36,7 +36,7 @@ struct tc_loop_comm {
     int nranks;
     pthread_barrier_t bar;
     void *bufs[16];
-    double red[16][4];
+    double red[16][8];
 };
 
 
@@ -93,14 +93,14 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     if (!c) return TCGPU_ERR_NOMEM;
     c->device = device;
     c->nranks = 1;
-    c->timing = 1;
+    c->timing = 0;                               /* option "timing": HIP events per phase, off in the product path */
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         free(c);
         return TCGPU_ERR_HIP;
     }
     bool ok = hipMalloc(&c->d_halo, sizeof(tc_halo_dev) * TC_MAX_HALOS_DEV) == hipSuccess;
-    ok = ok && hipMalloc(&c->red, sizeof(double) * (4 * TC_RED_BLOCKS + 16)) == hipSuccess;
-    ok = ok && hipHostMalloc(&c->h_red, sizeof(double) * 16) == hipSuccess;
+    ok = ok && hipMalloc(&c->red, sizeof(double) * (4 * TC_RED_BLOCKS + 32)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->h_red, sizeof(double) * 32) == hipSuccess;
     ok = ok && hipMalloc(&c->flags, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&c->h_flags, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMalloc(&c->orphans, sizeof(uint32_t) * TC_MAX_ORPHANS) == hipSuccess;
@@ -241,15 +241,22 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
      * queries at a deeper level use the cell-by-cell path */
     int lmax_rm = lmax;
     if ((double)n < 0.03 * pow(8.0, (double)lmax)) lmax_rm = lmax - 1;
-    if ((double)lmax_rm * (double)(c->cap + 1) >= 4.0e9) lmax_rm = 0; /* slots are 32-bit */
     if (!c->rows) lmax_rm = 0;
-    c->lmax_rm = lmax_rm;
     /* the coarsest levels are queried by next to no particle (balls wider than 1/16 of the box): not worth a
      * copy of every particle per level; those few queries take the cell-by-cell path */
-    c->lmin_rm = lmax_rm > 5 ? lmax_rm - 4 : 1;
+    int lmin_rm = lmax_rm > 5 ? lmax_rm - 4 : 1;
+    if (lmax_rm > 0 && (double)(lmax_rm - lmin_rm + 1) * (double)(c->cap + 1) >= 4.0e9) {   /* slots are 32-bit */
+        fprintf(stderr, "tcgpu: notice: %lld particles x %d mirrored levels exceed the 32-bit slot range; "
+                        "row-run fast path disabled (cell-by-cell path only)\n", (long long)n, lmax_rm - lmin_rm + 1);
+        lmax_rm = 0;
+    }
+    c->lmax_rm = lmax_rm;
+    c->lmin_rm = lmin_rm;
     c->mirror_valid = 0;
     if (lmax_rm > 0) {
-        size_t ncum = tc_level_offset(lmax_rm + 1) + 1, nslot = (size_t)lmax_rm * (size_t)c->cap;
+        /* only the mirrored levels lmin_rm..lmax_rm are scanned and own slots */
+        size_t ncum = tc_level_offset(lmax_rm + 1) - tc_level_offset(lmin_rm) + 1;
+        size_t nslot = (size_t)(lmax_rm - lmin_rm + 1) * (size_t)c->cap;
         if (ncum > c->cum_alloc) {
             hipFree(c->cum); hipFree(c->scan_tmp);
             c->cum = nullptr; c->scan_tmp = nullptr; c->cum_alloc = 0;
@@ -353,7 +360,9 @@ extern "C" int tcgpu_download_particles(tcgpu_ctx *c, float *pos, int32_t *id, f
 
 /* ------------------------------------------------------------------ flags */
 
-static int check_flags(tcgpu_ctx *c)
+/* `reduced`: the four error flags already maximised over the ranks (multi-rank contexts: every rank must take
+ * the same exit, or the ranks that carry on would wait forever in the next collective); NULL = this rank's own. */
+static int check_flags(tcgpu_ctx *c, const double *reduced = nullptr)
 {
     TC_HIP(c, hipMemcpyAsync(c->h_flags, c->flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
     TC_HIP(c, hipStreamSynchronize(c->stream));
@@ -361,6 +370,8 @@ static int check_flags(tcgpu_ctx *c)
     int f[8];
     memcpy(f, c->h_flags, sizeof(f));
     if (f[0] || f[1] || f[2] || f[3]) TC_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+    if (reduced)
+        for (int q = 0; q < 4; q++) f[q] = reduced[q] != 0;
     if (f[1]) TC_FAIL(c, TCGPU_ERR_COORD_RANGE, "coordinate outside [0,boxsize] (reference: peano.c:130-132 Assert)");
     if (f[0]) TC_FAIL(c, TCGPU_ERR_NONFINITE, "hsml not finite (reference: sph.c:28 Assert)");
     if (f[3]) TC_FAIL(c, TCGPU_ERR_OVERFLOW, "more than %d particles sit exactly on the upper box face", TC_MAX_ORPHANS);
@@ -448,29 +459,51 @@ static int allgather_inplace(tcgpu_ctx *c, void *base, size_t esize)
     return 0;
 }
 
-/* all-reduce of the error sums: fin[0], fin[1] summed, fin[3] maximised over the ranks */
-static int allreduce_error_sums(tcgpu_ctx *c, double *fin)
+/* all-reduce of the scalars of one pass, in place on the device: buf[0..2] summed (error sum, particle count,
+ * spare), buf[3..7] maximised (largest error and the four error flags as 0/1, see check_flags) */
+static int allreduce_pass_scalars(tcgpu_ctx *c, double *buf)
 {
     if (c->loop) {
         tc_loop_comm *L = c->loop;
-        double h[4];
-        TC_HIP(c, hipMemcpyAsync(h, fin, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        double h[8];
+        TC_HIP(c, hipMemcpyAsync(h, buf, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         TC_HIP(c, hipStreamSynchronize(c->stream));
         memcpy(L->red[c->rank], h, sizeof(h));
         pthread_barrier_wait(&L->bar);
-        double o[4] = {0, 0, 0, 0};
-        for (int p = 0; p < L->nranks; p++) { o[0] += L->red[p][0]; o[1] += L->red[p][1]; o[3] = fmax(o[3], L->red[p][3]); }
+        double o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = 0; p < L->nranks; p++) {
+            for (int q = 0; q < 3; q++) o[q] += L->red[p][q];
+            for (int q = 3; q < 8; q++) o[q] = fmax(o[q], L->red[p][q]);
+        }
         pthread_barrier_wait(&L->bar);
-        TC_HIP(c, hipMemcpyAsync(fin, o, sizeof(o), hipMemcpyHostToDevice, c->stream));
+        TC_HIP(c, hipMemcpyAsync(buf, o, sizeof(o), hipMemcpyHostToDevice, c->stream));
         TC_HIP(c, hipStreamSynchronize(c->stream));
         return 0;
     }
     g_rccl.GroupStart();
-    ncclResult_t r1 = g_rccl.AllReduce(fin, fin, 2, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
-    ncclResult_t r2 = g_rccl.AllReduce(fin + 3, fin + 3, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream);
-    g_rccl.GroupEnd();
-    if (r1 != ncclSuccess || r2 != ncclSuccess) TC_FAIL(c, TCGPU_ERR_COMM, "ncclAllReduce failed");
+    ncclResult_t r1 = g_rccl.AllReduce(buf, buf, 3, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
+    ncclResult_t r2 = g_rccl.AllReduce(buf + 3, buf + 3, 5, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream);
+    ncclResult_t r3 = g_rccl.GroupEnd();
+    if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) TC_FAIL(c, TCGPU_ERR_COMM, "ncclAllReduce failed");
     return 0;
+}
+
+/* multi-rank contexts: agree on the error flags (maximum over the ranks), then check them; every rank
+ * returns the same status.  Single rank: the plain check. */
+static int check_flags_collective(tcgpu_ctx *c)
+{
+    if (!(c->comm || c->loop)) return check_flags(c);
+    double *buf = c->red + 4 * TC_RED_BLOCKS + 8;
+    TC_HIP(c, hipMemsetAsync(buf, 0, 8 * sizeof(double), c->stream));
+    int rc = tc_launch_flags_to_f64(c, buf + 4);
+    if (rc) return rc;
+    tc_phase_begin(c, PH_COMM);
+    rc = allreduce_pass_scalars(c, buf);
+    tc_phase_end(c);
+    if (rc) return rc;
+    TC_HIP(c, hipMemcpyAsync(c->h_red + 8, buf, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TC_HIP(c, hipStreamSynchronize(c->stream));
+    return check_flags(c, c->h_red + 8 + 4);
 }
 
 /* testing: tie `nranks` contexts of this process into a loopback communicator (one thread each) */
@@ -594,11 +627,15 @@ static int gather_sph(tcgpu_ctx *c, int gather_all)
     tc_phase_begin(c, PH_COMM);
     if (c->comm) g_rccl.GroupStart();
     int r1 = allgather_inplace(c, c->hsml[c->cur], sizeof(float)), r2 = 0, r3 = 0;
-    if (gather_all) {
+    if (gather_all && !r1) {
         r2 = allgather_inplace(c, c->rho[c->cur], sizeof(float));
-        r3 = allgather_inplace(c, c->vhf[c->cur], sizeof(float));
+        if (!r2) r3 = allgather_inplace(c, c->vhf[c->cur], sizeof(float));
     }
-    if (c->comm) g_rccl.GroupEnd();
+    /* the group is closed whatever happened in it */
+    if (c->comm && g_rccl.GroupEnd() != ncclSuccess && !(r1 || r2 || r3)) {
+        snprintf(c->err, sizeof(c->err), "ncclGroupEnd failed");
+        r1 = TCGPU_ERR_COMM;
+    }
     tc_phase_end(c);
     return (r1 || r2 || r3) ? TCGPU_ERR_COMM : 0;
 }
@@ -626,7 +663,7 @@ extern "C" int tcgpu_find_sph_quantities(tcgpu_ctx *c)
     TC_HIP(c, hipSetDevice(c->device));
     int rc = find_sph_quantities_nocheck(c, c->need_guess, 0, 1);
     if (rc) return rc;
-    rc = check_flags(c);
+    rc = check_flags_collective(c);
     if (rc) return rc;
     c->need_guess = 0;                            /* every hsml is > 0 after a successful pass */
     if (c->want_stats) return density_stats(c);
@@ -734,15 +771,19 @@ static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, do
     int rc;
     if ((rc = find_sph_quantities_nocheck(c, need_guess, 1, 0))) return rc;
     if ((rc = tc_launch_error(c))) return rc;
-    double *fin = c->red + 4 * TC_RED_BLOCKS;
-    if (c->comm || c->loop) {
+    double *fin = c->red + 4 * TC_RED_BLOCKS;                 /* {sum err, count, 0, max err} */
+    const bool multi = c->comm || c->loop;
+    if (multi) {
+        /* the error flags ride along (fin[4..7], maximised): every rank sees the same flags and takes the
+         * same exit -- a rank that returned alone would leave the others waiting in the next collective */
+        if ((rc = tc_launch_flags_to_f64(c, fin + 4))) return rc;
         tc_phase_begin(c, PH_COMM);
-        rc = allreduce_error_sums(c, fin);
+        rc = allreduce_pass_scalars(c, fin);
         tc_phase_end(c);
         if (rc) return rc;
     }
-    TC_HIP(c, hipMemcpyAsync(c->h_red, fin, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if ((rc = check_flags(c))) return rc;                     /* synchronises the stream */
+    TC_HIP(c, hipMemcpyAsync(c->h_red, fin, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = check_flags(c, multi ? c->h_red + 4 : nullptr))) return rc;      /* synchronises the stream */
     *err_mean = c->h_red[0] / c->h_red[1];                    /* wvt_relax.c:87 */
     *err_max = c->h_red[3];
     return 0;
@@ -754,6 +795,7 @@ extern "C" int tcgpu_density_error(tcgpu_ctx *c, double *err_mean, double *err_m
     TC_HIP(c, hipSetDevice(c->device));
     int rc = density_error_sync(c, c->need_guess, err_mean, err_max);
     if (!rc) c->need_guess = 0;
+    if (!rc && c->want_stats) return density_stats(c);
     return rc;
 }
 

@@ -897,7 +897,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->norph = c->norph;
     k->pos4 = c->pos4[c->cur];
     const bool rm = c->rows && c->mirror_valid && c->lmax_rm > 0;
-    k->cum = rm ? c->cum : nullptr;
+    k->cum = rm ? tc_cum_base(c) : nullptr;
     k->mirror = rm ? c->mirror : nullptr;
     k->mirror_idx = rm ? c->mirror_idx : nullptr;
     k->lmax_rm = rm ? c->lmax_rm : 0;

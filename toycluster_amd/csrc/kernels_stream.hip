@@ -235,14 +235,17 @@ int tc_launch_mirror(tcgpu_ctx *c)
     c->mirror_valid = 0;
     if (!c->rows || c->lmax_rm <= 0 || !c->index_valid) return 0;
     const int n = (int)c->n;
-    const size_t ncell = tc_level_offset(c->lmax_rm + 1) + 1;          /* +1: the end of the last cell */
+    /* scan only the mirrored levels; `cum` is addressed with whole-table cell offsets through a pointer
+     * shifted back by the offset of the first mirrored level (tc_cum_base) */
+    const size_t first = tc_level_offset(c->lmin_rm);
+    const size_t ncell = tc_level_offset(c->lmax_rm + 1) - first + 1;     /* +1: the end of the last cell */
     tc_phase_begin(c, PH_MIRROR);
-    auto in = rocprim::make_transform_iterator((const uint2 *)c->cells, tc_cell_count());
+    auto in = rocprim::make_transform_iterator((const uint2 *)c->cells + first, tc_cell_count());
     size_t b = c->scan_tmp_bytes;
     hipError_t e = rocprim::exclusive_scan(c->scan_tmp, b, in, c->cum, 0u, ncell, rocprim::plus<uint32_t>(), c->stream);
     if (e == hipSuccess)
         k_mirror<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->lmin_rm, c->lmax_rm,
-                                                         c->cells, c->cum, c->mirror, c->mirror_idx);
+                                                         c->cells, tc_cum_base(c), c->mirror, c->mirror_idx);
     tc_phase_end(c);
     TC_HIP(c, e);
     TC_HIP(c, hipGetLastError());
@@ -371,6 +374,19 @@ __global__ __launch_bounds__(TB) void k_final4(const double *__restrict__ part, 
     block_reduce4(s0, s1, s2, mx, fin);
 }
 
+/* the four error flags as 0/1 doubles, so that they can ride in the pass's all-reduce (api.hip) */
+__global__ void k_flags_to_f64(const int *__restrict__ flags, double *__restrict__ out)
+{
+    if (threadIdx.x < 4) out[threadIdx.x] = flags[threadIdx.x] != 0 ? 1.0 : 0.0;
+}
+
+int tc_launch_flags_to_f64(tcgpu_ctx *c, double *d_out)
+{
+    k_flags_to_f64<<<1, 64, 0, c->stream>>>(c->flags, d_out);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
 /* ------------------------------------------------------------------ density model (API) */
 
 __global__ __launch_bounds__(TB) void k_model(const float4 *__restrict__ pos4, int n, double boxhalf,
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(TB) void k_scale_hsml(float4 *__restrict__ pos4, in
 int tc_launch_model_hsml(tcgpu_ctx *c)
 {
     int n = (int)c->n, nb = TC_RED_BLOCKS;
-    double *fin = c->red + 4 * TC_RED_BLOCKS + 4;
+    double *fin = c->red + 4 * TC_RED_BLOCKS + 16;        /* [0..7] error pass, [8..15] flag agreement, [16..19] here */
     tc_phase_begin(c, PH_MODEL_HSML);
     /* Rho_Model goes to a side buffer: the reference stores it when the sweep runs (wvt_relax.c:113),
      * so it is committed by tc_launch_commit_rhom(), not on iterations that stop before the sweep */

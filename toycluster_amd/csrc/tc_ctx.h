@@ -101,8 +101,8 @@ struct tcgpu_ctx {
     int *norph;
     int *work_ctr;                /* 8 x 16 ints: per-XCD-group particle counters of the dynamic work queue */
     int index_valid;
-    uint32_t *cum;                /* ncells(lmax_rm)+1 */
-    float4 *mirror;               /* lmax_rm x cap */
+    uint32_t *cum;                /* cells of levels lmin_rm..lmax_rm, +1 */
+    float4 *mirror;               /* (lmax_rm - lmin_rm + 1) x cap slots, +1 pad */
     uint32_t *mirror_idx;
     void *scan_tmp;
     size_t scan_tmp_bytes, cum_alloc, mirror_alloc;
@@ -118,8 +118,8 @@ struct tcgpu_ctx {
     /* scratch */
     float *guess;
     float *hwvt, *delta;          /* cap, 3*cap */
-    double *red;                  /* TC_RED_BLOCKS*4 partials + 8 finals */
-    double *h_red;                /* pinned, 8 doubles */
+    double *red;                  /* TC_RED_BLOCKS*4 partials + 32 finals */
+    double *h_red;                /* pinned, 32 doubles */
     int *flags;                   /* device: [0]=nonfinite [1]=coord range [2]=no convergence [3]=overflow [4]=wvt ngbmax hits */
     int *h_flags;                 /* pinned */
     uint32_t *stats;              /* 4 x cap, optional */
@@ -160,6 +160,9 @@ struct tcgpu_ctx {
         return (code);                                           \
     } while (0)
 
+/* `cum` holds the prefix sum of the mirrored levels only; kernels index it with whole-table cell offsets */
+static inline const uint32_t *tc_cum_base(const tcgpu_ctx *c) { return c->cum - tc_level_offset(c->lmin_rm); }
+
 /* ---- launchers implemented in the kernel translation units ---- */
 int tc_sort_temp_bytes(size_t n, size_t *bytes);
 int tc_sort_pairs_u128(void *tmp, size_t tmp_bytes, const tc_u128 *kin, tc_u128 *kout,
@@ -176,6 +179,7 @@ int tc_launch_model(tcgpu_ctx *c, float *d_out);
 int tc_launch_error(tcgpu_ctx *c);              /* -> red[0..2] = sum err, count, max err (over the shard) */
 int tc_launch_model_hsml(tcgpu_ctx *c);         /* rhom, hwvt (normalised, also into pos4.w) */
 int tc_launch_move(tcgpu_ctx *c);
+int tc_launch_flags_to_f64(tcgpu_ctx *c, double *d_out);   /* flags[0..3] != 0 as doubles */
 int tc_launch_commit_rhom(tcgpu_ctx *c);
 int tc_launch_density(tcgpu_ctx *c);
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt);   /* fused density (+ unit-step WVT sums) */

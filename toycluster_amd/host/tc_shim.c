@@ -14,6 +14,7 @@
 #include <string.h>
 #include "../../include/tcgpu.h"
 #include "tc_ref_abi.h"
+#include "../csrc/tc_math.h"
 
 static tcgpu_ctx *g_ctx;
 static int64_t g_uploaded_n;
@@ -184,4 +185,57 @@ float Global_density_model(const int ipart)
         rho = fmax(rho_i, rho);
     }
     return rho;
+}
+
+/* ---- src/sort.h:7-8, src/sort.c:185-195.  The live part of the reference's Qsort_Index is one call of GSL's
+ * gsl_heapsort_index (everything behind the early return is dead code); its only caller outside the replaced
+ * files is sort_particles() (src/positions.c:409: int halo ids, comparator compare_int, massive ties).  The
+ * published index-heapsort scheme, restated for an arbitrary comparator: p[] starts as the identity, a max-heap
+ * is built on p[0..last] with the children of slot k taken at 2k and 2k+1, from k = last/2 down to 0; then the
+ * root is swapped with the last entry and sifted down.  Unstable; the order of ties is a property of this
+ * procedure alone, which is why the gas block's file order needs exactly it (toycluster_amd/host/tc_reassign.c
+ * holds the same scheme specialised for int keys; tests/test_reassign.py compares the two). ---- */
+static void qi_sift_down(size_t *p, const char *data, size_t size, size_t last, size_t k,
+                         int (*cmp)(const void *, const void *))
+{
+    const size_t pk = p[k];
+    while (k <= last / 2) {
+        size_t j = 2 * k;
+        if (j < last && cmp(data + size * p[j], data + size * p[j + 1]) < 0) j++;
+        if (!(cmp(data + size * pk, data + size * p[j]) < 0)) break;
+        p[k] = p[j];
+        k = j;
+    }
+    p[k] = pk;
+}
+
+void Qsort_Index(const int nThreads, size_t *perm, void *const data, const int nData, const size_t datasize,
+                 int (*cmp)(const void *, const void *))
+{
+    (void)nThreads;                                   /* the reference sorts under `omp single` */
+    if (nData <= 0) return;
+    const size_t n = (size_t)nData;
+    for (size_t i = 0; i < n; i++) perm[i] = i;
+    size_t last = n - 1, k = last / 2 + 1;
+    do {
+        k--;
+        qi_sift_down(perm, data, datasize, last, k, cmp);
+    } while (k > 0);
+    while (last > 0) {
+        const size_t t = perm[0]; perm[0] = perm[last]; perm[last] = t;
+        last--;
+        qi_sift_down(perm, data, datasize, last, 0, cmp);
+    }
+}
+
+/* ---- src/peano.h:6, src/peano.c:128-203: host arithmetic shared with the device kernels (csrc/tc_math.h);
+ * no caller outside the replaced files, exported for completeness of peano.h ---- */
+peanoKey Peano_Key(const double x, const double y, const double z)
+{
+    if (!(x >= 0 && x <= 1 && y >= 0 && y <= 1 && z >= 0 && z <= 1)) fail(__func__, "coordinate outside [0,1]");
+    const double m = 9223372036854775808.0;           /* 2^63, src/peano.c:134-136 */
+    uint64_t X[3] = {(uint64_t)(y * m), (uint64_t)(z * m), (uint64_t)(x * m)}, hi, lo;
+    tc_hilbert_transpose(X);
+    tc_key_from_transpose(X, &hi, &lo);
+    return ((peanoKey)hi << 64) | lo;
 }
