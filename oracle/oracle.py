@@ -227,6 +227,35 @@ def reassign_to_halos(model, pos):
     return hid, perm, npart
 
 
+def set_vector_potential(model, pos, eta):
+    """magnetic_field.c:33-69."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+    a = np.empty_like(pos)
+    L = lib()
+    L.orc_set_vector_potential.restype = None
+    L.orc_set_vector_potential.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_double, C.c_void_p]
+    L.orc_set_vector_potential(len(pos), _p(pos), model.boxsize, len(model.halos), C.cast(_orc_halos(model), C.c_void_p),
+                               float(eta), _p(a))
+    return a
+
+
+def normalise_magnetic_field(model, pos, bfld, bfld_norm, r_sample_dm, sub_first=2):
+    """magnetic_field.c:71-131 on a copy of bfld: (bfld, norm, n_limited)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+    b = np.array(bfld, dtype=np.float32, order="C", copy=True)
+    rg = np.array([h.r_sample for h in model.halos], np.float64)
+    rd = np.ascontiguousarray(r_sample_dm, np.float64)
+    norm, cnt = C.c_double(), C.c_int()
+    L = lib()
+    L.orc_normalise_magnetic_field.restype = None
+    L.orc_normalise_magnetic_field.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.orc_normalise_magnetic_field(len(pos), _p(pos), _p(b), model.boxsize, len(model.halos),
+                                   C.cast(_orc_halos(model), C.c_void_p), _p(rg), _p(rd), int(sub_first), float(bfld_norm),
+                                   C.byref(norm), C.byref(cnt))
+    return b, norm.value, cnt.value
+
+
 def format_log_line(l):
     """The reference's per-iteration line, wvt_relax.c:91-92."""
     return "   #%02d: Err max=%3g mean=%03g diff=%03g step=%g" % (

@@ -935,3 +935,98 @@ int orc_reassign_to_halos(int n, const float *pos, double boxsize, int nhalos, c
     free(idx);
     return 0;
 }
+
+/* ---- the wrapper around the curl: magnetic_field.c:33-131 (test infrastructure, like the rest of this file) ---- */
+
+#define ORC_P2(a) ((a) * (a))                               /* macro.h p2() */
+
+/* Halo_containing, positions.c:333-388, both branches; r_sample_gas = R_Sample[0], r_sample_dm = R_Sample[1] */
+static int orc_halo_containing(int type, float x, float y, float z, double boxsize, int nhalos, const orc_halo *Halo,
+                               const double *r_sample_gas, const double *r_sample_dm, int sub_first)
+{
+    if ((x > boxsize || y > boxsize || z > boxsize)) return -1;
+    int i = 0;
+    if (type > 0) {                                         /* DM, positions.c:343-362 */
+        if (nhalos > 1) {
+            float r = sqrt(ORC_P2(x - Halo[1].d_com[0]) + ORC_P2(y - Halo[1].d_com[1]) + ORC_P2(z - Halo[1].d_com[2]));
+            if ((r < r_sample_dm[1]) && (x > 0)) i = 1;
+        }
+        for (int j = sub_first; j < nhalos; j++) {
+            float r = sqrt(ORC_P2(x - Halo[j].d_com[0]) + ORC_P2(y - Halo[j].d_com[1]) + ORC_P2(z - Halo[j].d_com[2]));
+            if (r < r_sample_dm[j]) {
+                i = j;
+                break;
+            }
+        }
+    } else {                                                /* SPH, positions.c:364-385 */
+        double rho_max = 0;
+        for (int j = 0; j < nhalos; j++) {
+            float r = sqrt(ORC_P2(x - Halo[j].d_com[0]) + ORC_P2(y - Halo[j].d_com[1]) + ORC_P2(z - Halo[j].d_com[2]));
+            double rho_gas = gas_density_profile(r, Halo[j].rho0, Halo[j].beta, Halo[j].rcore, Halo[j].rcut);
+            if ((rho_gas > rho_max) && (r < r_sample_gas[j])) {
+                i = j;
+                rho_max = rho_gas;
+            }
+        }
+    }
+    return i;
+}
+
+/* set_magnetic_vector_potential, magnetic_field.c:33-69 */
+void orc_set_vector_potential(int n, const float *pos, double boxsize, int nhalos, const orc_halo *Halo, double eta,
+                              float *apot)
+{
+    const float boxhalf = 0.5 * boxsize;
+    for (int ipart = 0; ipart < n; ipart++) {
+        double A_max = 0;
+        for (int i = 0; i < nhalos; i++) {
+            if (Halo[i].mass_gas == 0) continue;
+            float dx = pos[3 * ipart] - Halo[i].d_com[0] - boxhalf, dy = pos[3 * ipart + 1] - Halo[i].d_com[1] - boxhalf,
+                  dz = pos[3 * ipart + 2] - Halo[i].d_com[2] - boxhalf;
+            double r2 = dx * dx + dy * dy + dz * dz;
+            double rho_i = gas_density_profile(sqrt(r2), Halo[i].rho0, Halo[i].beta, Halo[i].rcore, Halo[i].rcut);
+            double A = pow(rho_i / Halo[i].rho0, eta);
+            if (A > A_max) A_max = A;
+        }
+        apot[3 * ipart] = (float)A_max;
+        apot[3 * ipart + 1] = (float)A_max;
+        apot[3 * ipart + 2] = (float)A_max;
+    }
+}
+
+/* normalise_magnetic_field, magnetic_field.c:71-131, serial (the reference's max_B2 update races, SURVEY.md section 5;
+ * serial = the race-free value).  Halo_containing is called with the particle INDEX as `type`, as the reference does
+ * (magnetic_field.c:109). */
+void orc_normalise_magnetic_field(int n, const float *pos, float *bfld, double boxsize, int nhalos, const orc_halo *Halo,
+                                  const double *r_sample_gas, const double *r_sample_dm, int sub_first, double bfld_norm,
+                                  double *norm_out, int *cnt_out)
+{
+    const float boxhalf = 0.5 * boxsize;
+    double max_B2 = 0;
+    for (int ipart = 0; ipart < n; ipart++) {
+        double bfld2 = ORC_P2(bfld[3 * ipart]) + ORC_P2(bfld[3 * ipart + 1]) + ORC_P2(bfld[3 * ipart + 2]);
+        max_B2 = fmax(max_B2, bfld2);
+    }
+    double max_bfld = sqrt(max_B2);
+    double norm = bfld_norm / max_bfld / sqrt(3);
+    int cnt = 0;
+    for (int ipart = 0; ipart < n; ipart++) {
+        bfld[3 * ipart] *= norm;
+        bfld[3 * ipart + 1] *= norm;
+        bfld[3 * ipart + 2] *= norm;
+        double B2 = ORC_P2(bfld[3 * ipart]) + ORC_P2(bfld[3 * ipart + 1]) + ORC_P2(bfld[3 * ipart + 2]);
+        float x = pos[3 * ipart] - boxhalf, y = pos[3 * ipart + 1] - boxhalf, z = pos[3 * ipart + 2] - boxhalf;
+        int i = orc_halo_containing(ipart, x, y, z, boxsize, nhalos, Halo, r_sample_gas, r_sample_dm, sub_first);
+        double bmax = 18e-6;                                /* BMAX, magnetic_field.c:4 */
+        if (i > 1) bmax = 2e-6;
+        if ((B2 > ORC_P2(bmax))) {
+            double B = sqrt(B2);
+            bfld[3 * ipart] *= bmax / B;
+            bfld[3 * ipart + 1] *= bmax / B;
+            bfld[3 * ipart + 2] *= bmax / B;
+            cnt++;
+        }
+    }
+    *norm_out = norm;
+    *cnt_out = cnt;
+}

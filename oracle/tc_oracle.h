@@ -107,4 +107,11 @@ int orc_reassign_to_halos(int n, const float *pos, double boxsize, int nhalos, c
 void orc_last_stats(const orc_state *s, double *queries_per_part, double *solver_iters_per_part,
                     double *pair_evals_per_part);
 
+/* magnetic_field.c:33-131 */
+void orc_set_vector_potential(int n, const float *pos, double boxsize, int nhalos, const orc_halo *halos, double eta,
+                              float *apot);
+void orc_normalise_magnetic_field(int n, const float *pos, float *bfld, double boxsize, int nhalos, const orc_halo *halos,
+                                  const double *r_sample_gas, const double *r_sample_dm, int sub_first, double bfld_norm,
+                                  double *norm_out, int *cnt_out);
+
 #endif

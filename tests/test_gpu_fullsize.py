@@ -87,6 +87,46 @@ def check_common(g, m, ids_in, n, nsample=5):
     return p, picks
 
 
+def test_probe_rows_of_the_running_reference():
+    """SURVEY.md section 6 / 3.3, the only numbers measured on the reference itself (8 threads): the 1e6-gas merger
+    (Mass_Ratio 0.3125, Ntotal 2000000) stops after 27 iterations (#00..#26, errDiff < 0.01 && it > 25) at mean
+    error 0.075; config 1 (Ntotal 200000) costs 4 919 pair evaluations per particle on the cold pass and 1.61 ball
+    queries / 2.82 Find_hsml iterations / 1 270 pair evaluations on the warm one.  Same caveat as the oracle's twin
+    of this test (tests/test_oracle.py): it shows drift, it does not pin parity."""
+    s = hostio.setup_system(PAR, {"ntotal": 2_000_000, "mass_ratio": 0.3125})
+    pos, ids = hostio.sample_gas(s, nthreads=8)
+    g = binding.TcGpu(0)
+    try:
+        g.set_model(hostio.setup_to_model(s))
+        g.upload(pos, ids)
+        log = g.Regularise_sph_particles()
+        assert len(log) == 27 and log[-1]["err_diff"] < 0.01
+        assert abs(log[-1]["err_mean"] - 0.075) < 0.003
+        s = hostio.setup_system(PAR, {"ntotal": 200_000})
+        pos, ids = hostio.sample_gas(s, nthreads=8)
+        g.set_option("stats", 1)
+        g.set_option("fuse", 0)                                 # one plain kernel per reference loop: counts per pass
+        g.set_model(hostio.setup_to_model(s))
+        g.upload(pos, ids)
+        g.Find_sph_quantities()
+        cold = g.density_stats()
+        g.Find_sph_quantities()
+        warm = g.density_stats()
+        assert cold["pair_evals"] == pytest.approx(4919, rel=0.02)
+        assert warm["queries"] == pytest.approx(1.61, rel=0.02)
+        assert warm["solver_iters"] == pytest.approx(2.82, rel=0.02)
+        assert warm["pair_evals"] == pytest.approx(1270, rel=0.02)
+        g.set_option("fuse", 1)                                 # the fused kernel replays the same control flow
+        g.upload(pos, ids)
+        g.Find_sph_quantities()
+        g.Find_sph_quantities()
+        fused = g.density_stats()
+        assert fused["queries"] == pytest.approx(warm["queries"], rel=1e-3)
+        assert fused["pair_evals"] == pytest.approx(warm["pair_evals"], rel=1e-3)
+    finally:
+        g.close()
+
+
 def test_config3_size_one_gpu():
     """1.6e7 SPH particles, 2-cluster merger (the particle count of BASELINE config 3) on ONE GPU."""
     n = 16_000_000

@@ -123,6 +123,8 @@ typedef struct {
     float *pos;                       /* 3*ngas, in [0, boxsize] */
     int32_t *id;                      /* ngas */
     double *r_sample;                 /* Halo[i].R_Sample[0] per halo, or NULL (optional trailer of the file) */
+    double *r_sample_dm;              /* Halo[i].R_Sample[1]; in memory only (native set-up), NULL from a state file */
+    int sub_first;                    /* Sub.First (src/aux.c:10: 2 unless Setup_Substructure ran) */
 } tc_state;
 
 int  tc_read_state(const char *filename, tc_state *st, char *err, size_t errlen);
@@ -136,5 +138,14 @@ void tc_heapsort_index_i32(size_t *p, const int32_t *key, size_t n);
 int  tc_reassign_particles_to_halos(const tcgpu_params *par, const tcgpu_halo *halos, const double *r_sample,
                                     size_t n, const float *pos, int32_t *halo_id, size_t *perm, long long *npart);
 int  tc_permute_rows(void *data, size_t n, size_t width, const size_t *perm);
+
+/* ---- the wrapper around the curl: src/magnetic_field.c:33-131 ---- */
+void tc_set_magnetic_vector_potential(const tcgpu_params *par, const tcgpu_halo *halos, double bfld_eta, size_t n,
+                                      const float *pos, float *apot);
+int  tc_halo_containing_dm(const tcgpu_params *par, const tcgpu_halo *halos, const double *r_sample_dm, int sub_first,
+                           float x, float y, float z);
+int  tc_normalise_magnetic_field(const tcgpu_params *par, const tcgpu_halo *halos, const double *r_sample_gas,
+                                 const double *r_sample_dm, int sub_first, double bfld_norm, size_t n, const float *pos,
+                                 float *bfld, double *norm_out, long long *nlimited);
 
 #endif

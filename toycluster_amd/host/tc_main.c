@@ -31,13 +31,6 @@ static void die(int code, const char *what, const char *msg)
     exit(code);
 }
 
-/* src/setup.c:598-615 */
-static double gas_density_profile(double r, const tcgpu_halo *h)
-{
-    double a = r / h->rcore, b = r / h->rcut;
-    return h->rho0 * pow(1 + a * a, -3.0 / 2.0 * h->beta) / (1 + (b * b * b) * b);
-}
-
 int main(int argc, char **argv)
 {
     if (argc < 2) {
@@ -87,7 +80,10 @@ int main(int argc, char **argv)
         tc_setup_to_model(&S, &st.par, st.halos);
         st.r_sample = malloc((size_t)S.nhalos * sizeof(double));
         if (!st.r_sample) die(EXIT_FAILURE, "malloc", "out of memory");
-        for (int i = 0; i < S.nhalos; i++) st.r_sample[i] = S.halo[i].r_sample[0];
+        st.r_sample_dm = malloc((size_t)S.nhalos * sizeof(double));
+        if (!st.r_sample_dm) die(EXIT_FAILURE, "malloc", "out of memory");
+        for (int i = 0; i < S.nhalos; i++) { st.r_sample[i] = S.halo[i].r_sample[0]; st.r_sample_dm[i] = S.halo[i].r_sample[1]; }
+        st.sub_first = S.sub_nhalos > 0 ? S.sub_first : 2;                          /* src/aux.c:10, substructure.c:33-36 */
         const char *nt = getenv("OMP_NUM_THREADS");
         printf("Sampling positions "); fflush(stdout);
         tc_sample_gas_seeded(&S, nt ? atoi(nt) : 1, seed0, st.pos, st.id);
@@ -129,43 +125,18 @@ int main(int argc, char **argv)
 
     /* ---- Make_magnetic_field() */
     printf("Magnetic field: \n   B0              = %g G\n   eta             = %g \n\n", par.bfld_norm, par.bfld_eta);
-    const float boxhalf = 0.5 * st.par.boxsize;
-    for (size_t i = 0; i < n; i++) {                                   /* src/magnetic_field.c:38-66 */
-        double a_max = 0;
-        for (int k = 0; k < st.par.nhalos; k++) {
-            const tcgpu_halo *h = &st.halos[k];
-            if (h->mass_gas == 0) continue;
-            float dx = pos[3 * i] - h->d_com[0] - boxhalf, dy = pos[3 * i + 1] - h->d_com[1] - boxhalf,
-                  dz = pos[3 * i + 2] - h->d_com[2] - boxhalf;
-            double r2 = dx * dx + dy * dy + dz * dz;
-            double a = pow(gas_density_profile(sqrt(r2), h) / h->rho0, par.bfld_eta);
-            if (a > a_max) a_max = a;
-        }
-        apot[3 * i] = apot[3 * i + 1] = apot[3 * i + 2] = (float)a_max;
-    }
+    tc_set_magnetic_vector_potential(&st.par, st.halos, par.bfld_eta, n, pos, apot);   /* src/magnetic_field.c:33-69 */
     printf("Constructing B from rot(A)"); fflush(stdout);
     CK(tcgpu_bfld_from_rotA_sph(ctx, apot, bfld));
     printf(" done \n\n");
-    double max_b2 = 0;                                                  /* src/magnetic_field.c:75-85, without the race */
-    for (size_t i = 0; i < n; i++) {
-        double b2 = (double)bfld[3 * i] * bfld[3 * i] + (double)bfld[3 * i + 1] * bfld[3 * i + 1]
-                    + (double)bfld[3 * i + 2] * bfld[3 * i + 2];
-        max_b2 = fmax(max_b2, b2);
-    }
-    double norm = par.bfld_norm / sqrt(max_b2) / sqrt(3);
+    /* src/magnetic_field.c:71-131 (tc_bfield.c): normalisation, 18e-6 G limit, 2e-6 G for "subhalo" particles as the
+     * reference's Halo_containing(ipart, ...) call classifies them */
+    double norm = 0;
+    long long cnt = 0;
+    tc_normalise_magnetic_field(&st.par, st.halos, st.r_sample, st.r_sample_dm, st.sub_first, par.bfld_norm, n, pos, bfld,
+                                &norm, &cnt);
     printf("Bfld Norm = %g \n", norm);
-    int cnt = 0;
-    for (size_t i = 0; i < n; i++) {                                    /* src/magnetic_field.c:96-126 */
-        for (int c = 0; c < 3; c++) bfld[3 * i + c] *= norm;
-        double B2 = (double)bfld[3 * i] * bfld[3 * i] + (double)bfld[3 * i + 1] * bfld[3 * i + 1]
-                    + (double)bfld[3 * i + 2] * bfld[3 * i + 2];
-        if (B2 > BMAX * BMAX) {
-            double B = sqrt(B2);
-            for (int c = 0; c < 3; c++) bfld[3 * i + c] *= BMAX / B;
-            cnt++;
-        }
-    }
-    printf("Bfld of %d particles limited to %g G\n", cnt, BMAX);
+    printf("Bfld of %lld particles limited to %g G\n", cnt, BMAX);
 
     /* ---- Reassign_particles_to_halos(): gas block reordered by halo (src/positions.c:264-331) */
     if (st.r_sample) {

@@ -13,7 +13,7 @@ static const char MAGIC[8] = {'T', 'C', 'S', 'T', 'A', 'T', 'E', '1'};
 
 void tc_free_state(tc_state *st)
 {
-    free(st->halos); free(st->pos); free(st->id); free(st->r_sample);
+    free(st->halos); free(st->pos); free(st->id); free(st->r_sample); free(st->r_sample_dm);
     memset(st, 0, sizeof(*st));
 }
 

@@ -221,6 +221,38 @@ def reassign_particles_to_halos(model, pos):
     return hid, perm.astype(np.int64), npart[:nh]
 
 
+def normalise_magnetic_field(model, pos, bfld, bfld_norm, r_sample_dm=None, sub_first=2):
+    """normalise_magnetic_field (src/magnetic_field.c:71-131) of the C host library, on copies.
+    Returns (bfld, norm, n_limited)."""
+    L = _lib()
+    par, halos = _model_structs(model)
+    pos = np.ascontiguousarray(pos, np.float32)
+    b = np.array(bfld, dtype=np.float32, order="C", copy=True)
+    rg = np.array([h.r_sample for h in model.halos], np.float64)
+    rd = None if r_sample_dm is None else np.ascontiguousarray(r_sample_dm, np.float64)
+    norm, cnt = C.c_double(), C.c_longlong()
+    L.tc_normalise_magnetic_field.argtypes = [C.POINTER(TcParams), C.POINTER(TcHalo), C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_double, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_longlong)]
+    L.tc_normalise_magnetic_field(C.byref(par), halos, rg.ctypes.data, None if rd is None else rd.ctypes.data,
+                                  int(sub_first), float(bfld_norm), len(pos), pos.ctypes.data, b.ctypes.data,
+                                  C.byref(norm), C.byref(cnt))
+    return b, norm.value, cnt.value
+
+
+def set_magnetic_vector_potential(model, pos, bfld_eta):
+    """set_magnetic_vector_potential (src/magnetic_field.c:33-69) of the C host library."""
+    L = _lib()
+    par, halos = _model_structs(model)
+    pos = np.ascontiguousarray(pos, np.float32)
+    a = np.empty((len(pos), 3), np.float32)
+    L.tc_set_magnetic_vector_potential.argtypes = [C.POINTER(TcParams), C.POINTER(TcHalo), C.c_double, C.c_size_t,
+                                                   C.c_void_p, C.c_void_p]
+    L.tc_set_magnetic_vector_potential.restype = None
+    L.tc_set_magnetic_vector_potential(C.byref(par), halos, float(bfld_eta), len(pos), pos.ctypes.data, a.ctypes.data)
+    return a
+
+
 def heapsort_index_i32(keys):
     L = _lib()
     keys = np.ascontiguousarray(keys, dtype=np.int32)
@@ -232,7 +264,8 @@ def heapsort_index_i32(keys):
 
 class State(C.Structure):
     _fields_ = [("par", TcParams), ("halos", C.POINTER(TcHalo)), ("ngas", C.c_int64), ("pos", C.POINTER(C.c_float)),
-                ("id", C.POINTER(C.c_int32)), ("r_sample", C.POINTER(C.c_double))]
+                ("id", C.POINTER(C.c_int32)), ("r_sample", C.POINTER(C.c_double)),
+                ("r_sample_dm", C.POINTER(C.c_double)), ("sub_first", C.c_int)]
 
 
 def read_state_header(path):
