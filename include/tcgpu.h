@@ -166,6 +166,11 @@ int tcgpu_set_option(tcgpu_ctx *ctx, const char *name, double value);
  * library's own stream): names/values arrays of length *n (in: capacity, out: used). */
 int tcgpu_phase_times(tcgpu_ctx *ctx, const char **names, double *seconds, int64_t *launches, int *n, int reset);
 void *tcgpu_stream(tcgpu_ctx *ctx);
+/* Sharded contexts: bytes this rank has received in collectives since the last reset (0 on a single rank). */
+double tcgpu_comm_bytes(tcgpu_ctx *ctx, int reset);
+/* Particles in the last pass's local set (own range + ghost shell; all n on a single rank), in the own range, and
+ * the number of passes that had to be repeated on the full set because a query left the ghost margin. */
+int tcgpu_local_set_info(tcgpu_ctx *ctx, int64_t *nloc, int64_t *nown, int32_t *retries);
 
 #ifdef __cplusplus
 }

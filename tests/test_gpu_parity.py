@@ -419,13 +419,14 @@ def test_rccl_code_path_single_rank(golden_case):
     assert (np.abs(p["pos"] - c["r_pos"]).max(axis=1) / c["r_hsml"]).max() < TOL_POS
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_sharded_path_with_loopback_ranks(nranks):
-    """The multi-GPU control flow (Peano-range shards, in-place all-gathers of hsml/rho/vhf and
-    positions, all-reduced error sums) run by `nranks` host threads on this one GPU through the
-    loopback communicator: every rank must end with the single-rank result."""
+@pytest.mark.parametrize("nranks,n", [(2, 20011), (3, 20011), (8, 60013)])
+def test_sharded_path_with_loopback_ranks(nranks, n):
+    """The multi-GPU control flow -- Peano-range shards of the global order, per-rank local sets (own range +
+    ghost shell from the interest mask) with their own sort / cell table / mirror, all-gathered positions,
+    exact all-reduced sums -- run by `nranks` host threads on this one GPU through the loopback communicator:
+    every rank must end with the single-rank result, bit for bit, log included."""
     import threading
-    n = 20011                                       # not a multiple of nranks: padded tail shard
+    # n is not a multiple of nranks: padded tail shard
     m = M.preset("merger", n)
     pos, ids = M.sample_gas(m, n, seed=23)
     g1 = binding.TcGpu(0)
@@ -446,8 +447,9 @@ def test_sharded_path_with_loopback_ranks(nranks):
             g.set_model(m)
             g.upload(pos, ids)
             log = g.Regularise_sph_particles(max_iter=4)
+            info = g.local_set_info()
             g.Find_sph_quantities()
-            out[r] = (log, g.particles())
+            out[r] = (log, g.particles(), info, g.comm_bytes())
         except Exception as e:                      # pragma: no cover
             out[r] = e
     th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
@@ -459,13 +461,18 @@ def test_sharded_path_with_loopback_ranks(nranks):
         c.close()
     for r in range(nranks):
         assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
-        log, p = out[r]
+        log, p, info, nbytes = out[r]
         assert len(log) == len(log1)
         for a, b in zip(log, log1):
-            assert a["step"] == b["step"] and a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-12)
-            assert a["err_max"] == b["err_max"]
-        for k in ("id", "pos", "hsml", "rho", "varhsmlfac"):
+            assert a["step"] == b["step"] and a["err_mean"] == b["err_mean"] and a["err_max"] == b["err_max"]
+        for k in ("id", "pos", "hsml", "rho", "varhsmlfac", "rho_model"):
             assert np.array_equal(p[k], p1[k]), (r, k)
+        # the warm passes ran on a local set, not on everything: own range < local set < all particles
+        assert info["nown"] == min((r + 1) * -(-n // nranks), n) - r * -(-n // nranks)
+        assert info["nown"] < info["nloc"] <= n and info["retries"] <= 1
+        assert nbytes > 0
+    if nranks == 8:
+        assert min(o[2]["nloc"] for o in out) < 0.8 * n          # at least the core ranks work on a compact set
 
 
 def test_curl_larger_case_vs_oracle(gpu):

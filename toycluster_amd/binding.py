@@ -52,7 +52,7 @@ EXPORTS = [
     "tcgpu_build_neighbour_index", "tcgpu_guess_hsml", "tcgpu_wvt_step", "tcgpu_density_error", "tcgpu_regularise_sph_particles",
     "tcgpu_bfld_from_rotA_sph", "tcgpu_comm_unique_id", "tcgpu_comm_init", "tcgpu_comm_init_loopback",
     "tcgpu_set_option",
-    "tcgpu_phase_times", "tcgpu_stream",
+    "tcgpu_phase_times", "tcgpu_stream", "tcgpu_comm_bytes", "tcgpu_local_set_info",
 ]
 
 _lib = None
@@ -97,6 +97,9 @@ def lib():
         L.tcgpu_phase_times.argtypes = [vp, vp, vp, vp, C.POINTER(i32), i32]
         L.tcgpu_stream.argtypes = [vp]
         L.tcgpu_stream.restype = vp
+        L.tcgpu_comm_bytes.argtypes = [vp, i32]
+        L.tcgpu_comm_bytes.restype = dbl
+        L.tcgpu_local_set_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -274,6 +277,14 @@ class TcGpu:
         n = C.c_int(cap)
         self._ck(self._L.tcgpu_phase_times(self._h, names, secs, launches, C.byref(n), int(reset)))
         return {names[i].decode(): (secs[i], launches[i]) for i in range(n.value)}
+
+    def local_set_info(self):
+        a, b, r = C.c_int64(), C.c_int64(), C.c_int32()
+        self._ck(self._L.tcgpu_local_set_info(self._h, C.byref(a), C.byref(b), C.byref(r)))
+        return dict(nloc=a.value, nown=b.value, retries=r.value)
+
+    def comm_bytes(self, reset=False):
+        return self._L.tcgpu_comm_bytes(self._h, int(reset))
 
     def stream(self):
         return self._L.tcgpu_stream(self._h)

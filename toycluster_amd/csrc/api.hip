@@ -2,6 +2,13 @@
  * api.hip -- C ABI of libtcgpu (include/tcgpu.h): context, buffers, and the host-side
  * control flow of the path (the loop of src/wvt_relax.c:61-218 and the driver part of
  * src/sph.c:13-17).  All device work is enqueued on the context's own HIP stream.
+ *
+ * Data model.  GLOBAL arrays hold all n particles in a fixed order G; positions are
+ * complete on every rank (all-gathered after each move), per-particle state is valid for the rank's own index
+ * range.  Every density pass builds a LOCAL set -- own range + the ghost shell its queries can reach; everything
+ * on a single rank and on cold passes -- sorts it along the Peano curve and builds the cell table and mirror
+ * over it; results go back to G by index.  G is re-sorted into Peano order only when somebody looks
+ * ("presentation": downloads, the per-particle API calls), which is also what makes the shards compact.
  */
 #include <dlfcn.h>
 #include <pthread.h>
@@ -14,7 +21,7 @@
 
 static const char *PHASE_NAMES[PH_COUNT] = {"peano_keys", "radix_sort", "permute", "cell_index", "hsml_guess",
                                             "density", "error_sums", "model_hsml", "wvt_sweep", "move",
-                                            "curl", "comm", "mirror"};
+                                            "curl", "comm", "mirror", "local_set", "presentation"};
 
 struct rccl_api {
     void *h;
@@ -36,7 +43,7 @@ struct tc_loop_comm {
     int nranks;
     pthread_barrier_t bar;
     void *bufs[16];
-    double red[16][8];
+    double red[16][16];
 };
 
 
@@ -78,7 +85,7 @@ void tc_phase_collect(tcgpu_ctx *c)
 
 /* ------------------------------------------------------------------ life cycle */
 
-extern "C" const char *tcgpu_version(void) { return "tcgpu 0.1 (gfx950)"; }
+extern "C" const char *tcgpu_version(void) { return "tcgpu 0.2 (gfx950)"; }
 
 extern "C" const char *tcgpu_last_error(const tcgpu_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
@@ -99,14 +106,17 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
         return TCGPU_ERR_HIP;
     }
     bool ok = hipMalloc(&c->d_halo, sizeof(tc_halo_dev) * TC_MAX_HALOS_DEV) == hipSuccess;
-    ok = ok && hipMalloc(&c->red, sizeof(double) * (4 * TC_RED_BLOCKS + 32)) == hipSuccess;
-    ok = ok && hipHostMalloc(&c->h_red, sizeof(double) * 32) == hipSuccess;
+    ok = ok && hipMalloc(&c->red, sizeof(double) * (4 * TC_RED_BLOCKS + 48)) == hipSuccess;
+    ok = ok && hipHostMalloc(&c->h_red, sizeof(double) * 48) == hipSuccess;
     ok = ok && hipMalloc(&c->flags, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&c->h_flags, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMalloc(&c->orphans, sizeof(uint32_t) * TC_MAX_ORPHANS) == hipSuccess;
     ok = ok && hipMalloc(&c->norph, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->work_ctr, 8 * 16 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->ngb_cnt, sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->lvl_range, 2 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_count, 4 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->imask, (tc_level_offset(TC_LP_MAX + 1) / 32 + 1) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&c->spill, sizeof(double) * (size_t)TC_MAX_PERSISTENT_BLOCKS * TC_WAVES_PER_BLOCK
                                         * (2 * TC_NGBMAX)) == hipSuccess;
     c->fuse = 1;
@@ -122,24 +132,24 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     return TCGPU_OK;
 }
 
+#define TC_FREE(p) do { hipFree(p); (p) = nullptr; } while (0)
+
 static void free_particles(tcgpu_ctx *c)
 {
     for (int b = 0; b < 2; b++) {
-        hipFree(c->pos4[b]); hipFree(c->id[b]); hipFree(c->hsml[b]); hipFree(c->rho[b]);
-        hipFree(c->vhf[b]); hipFree(c->rhom[b]);
-        c->pos4[b] = nullptr; c->id[b] = nullptr; c->hsml[b] = c->rho[b] = c->vhf[b] = c->rhom[b] = nullptr;
+        TC_FREE(c->g_pos4[b]); TC_FREE(c->g_id[b]); TC_FREE(c->g_hsml[b]); TC_FREE(c->g_rho[b]);
+        TC_FREE(c->g_vhf[b]); TC_FREE(c->g_rhom[b]);
     }
-    hipFree(c->apot); hipFree(c->bfld); hipFree(c->key); hipFree(c->key_sorted); hipFree(c->idx);
-    hipFree(c->idx_sorted); hipFree(c->sort_tmp); hipFree(c->cells); hipFree(c->guess);
-    hipFree(c->hwvt); hipFree(c->delta); hipFree(c->stats); hipFree(c->ngb_buf); hipFree(c->ustep); hipFree(c->rhom_next);
-    c->ustep = nullptr; c->rhom_next = nullptr;
-    c->apot = c->bfld = nullptr; c->key = c->key_sorted = nullptr; c->idx = c->idx_sorted = nullptr;
-    c->sort_tmp = nullptr; c->cells = nullptr; c->guess = c->hwvt = c->delta = nullptr;
-    c->stats = nullptr; c->ngb_buf = nullptr;
-    hipFree(c->cum); hipFree(c->scan_tmp); hipFree(c->mirror); hipFree(c->mirror_idx);
-    c->cum = nullptr; c->scan_tmp = nullptr; c->mirror = nullptr; c->mirror_idx = nullptr;
+    TC_FREE(c->g_key); TC_FREE(c->g_key_sorted);
+    TC_FREE(c->lsel); TC_FREE(c->lg); TC_FREE(c->own_list); TC_FREE(c->pos4); TC_FREE(c->hsml); TC_FREE(c->rho);
+    TC_FREE(c->vhf); TC_FREE(c->sel_tmp);
+    TC_FREE(c->apot); TC_FREE(c->bfld); TC_FREE(c->l_apot);
+    TC_FREE(c->key); TC_FREE(c->key_sorted); TC_FREE(c->idx); TC_FREE(c->idx_sorted); TC_FREE(c->sort_tmp);
+    TC_FREE(c->cells); TC_FREE(c->guess); TC_FREE(c->hwvt); TC_FREE(c->delta); TC_FREE(c->stats); TC_FREE(c->ngb_buf);
+    TC_FREE(c->ustep); TC_FREE(c->rhom_next);
+    TC_FREE(c->cum); TC_FREE(c->scan_tmp); TC_FREE(c->mirror); TC_FREE(c->mirror_idx);
     c->cum_alloc = c->mirror_alloc = 0; c->mirror_valid = 0;
-    c->cap = 0; c->n = 0; c->ncells_alloc = 0;
+    c->cap = 0; c->n = 0; c->nloc = 0; c->nown = 0; c->ncells_alloc = 0;
 }
 
 extern "C" void tcgpu_destroy(tcgpu_ctx *c)
@@ -150,6 +160,7 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     free_particles(c);
     hipFree(c->d_halo); hipFree(c->red); hipHostFree(c->h_red); hipFree(c->flags); hipHostFree(c->h_flags);
     hipFree(c->orphans); hipFree(c->norph); hipFree(c->work_ctr); hipFree(c->ngb_cnt); hipFree(c->spill);
+    hipFree(c->lvl_range); hipFree(c->d_count); hipFree(c->imask);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);
@@ -179,6 +190,16 @@ extern "C" int tcgpu_set_model(tcgpu_ctx *c, const tcgpu_params *par, const tcgp
     free(h);
     TC_HIP(c, e);
     c->have_model = 1;
+    c->w_valid = 0;
+    /* unit of the exact sum of h^3 (k_model_hsml): the model density is nowhere above the sum of the central
+     * densities, so h^3 = 295 m / rho / (4 pi / 3) is nowhere below h3_min; 2^-30 of that keeps 30 bits under
+     * the smallest term and 33 bits of head room above it in a 64-bit term. */
+    double rho_up = 0;
+    for (int i = 0; i < par->nhalos; i++)
+        if (halos[i].mass_gas != 0 && halos[i].rho0 > 0) rho_up += halos[i].rho0;
+    int e2 = 0;
+    if (rho_up > 0) (void)frexp(TC_DESNNGB * par->mpart_gas / rho_up / TC_FOURPITHIRD, &e2);
+    c->h3_unit = ldexp(1.0, e2 - 1 - 30);
     return TCGPU_OK;
 }
 
@@ -187,7 +208,9 @@ static int pick_lmax(int64_t n)
     /* Deepest table level: one below the mean inter-particle level, round(log8 n) + 1 (8 at N = 2e6, 9 at
      * 1.6e7, 10 at 1e8).  The densest few per cent of the particles would like one level more; clamped to
      * this one they see about twice the candidates, which costs less than clearing, scanning and mirroring a
-     * table eight times larger every iteration (measured at N = 2e6: -0.33 ms per iteration, tools/shift_probe.py). */
+     * table eight times larger every iteration (measured at N = 2e6: -0.33 ms per iteration, tools/shift_probe.py).
+     * Chosen from the TOTAL particle number on every rank: the cell decomposition -- hence the order in which a
+     * particle's neighbours are summed -- is then the same on one GPU and on eight. */
     int l = (int)floor(log((double)(n > 1 ? n : 1)) / log(8.0) + 0.5) + 1;
     if (l < 3) l = 3;
     if (l > TC_MAX_LEVEL) l = TC_MAX_LEVEL;
@@ -205,26 +228,41 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         free_particles(c);
         size_t cap = (size_t)need;
         for (int b = 0; b < 2; b++) {
-            TC_HIP(c, hipMalloc(&c->pos4[b], cap * sizeof(float4)));
-            TC_HIP(c, hipMalloc(&c->id[b], cap * sizeof(int32_t)));
-            TC_HIP(c, hipMalloc(&c->hsml[b], cap * sizeof(float)));
-            TC_HIP(c, hipMalloc(&c->rho[b], cap * sizeof(float)));
-            TC_HIP(c, hipMalloc(&c->vhf[b], cap * sizeof(float)));
-            TC_HIP(c, hipMalloc(&c->rhom[b], cap * sizeof(float)));
+            TC_HIP(c, hipMalloc(&c->g_pos4[b], cap * sizeof(float4)));
+            TC_HIP(c, hipMalloc(&c->g_id[b], cap * sizeof(int32_t)));
+            TC_HIP(c, hipMalloc(&c->g_hsml[b], cap * sizeof(float)));
+            TC_HIP(c, hipMalloc(&c->g_rho[b], cap * sizeof(float)));
+            TC_HIP(c, hipMalloc(&c->g_vhf[b], cap * sizeof(float)));
+            TC_HIP(c, hipMalloc(&c->g_rhom[b], cap * sizeof(float)));
         }
+        TC_HIP(c, hipMalloc(&c->g_key, cap * sizeof(tc_u128)));
+        TC_HIP(c, hipMalloc(&c->g_key_sorted, cap * sizeof(tc_u128)));
+        /* local set: sized for the full set (cold passes and single-rank contexts work on all particles) */
+        TC_HIP(c, hipMalloc(&c->lsel, cap * sizeof(uint32_t)));
+        TC_HIP(c, hipMalloc(&c->lg, cap * sizeof(uint32_t)));
+        TC_HIP(c, hipMalloc(&c->own_list, cap * sizeof(uint32_t)));
+        TC_HIP(c, hipMalloc(&c->pos4, cap * sizeof(float4)));
+        TC_HIP(c, hipMalloc(&c->hsml, cap * sizeof(float)));
+        TC_HIP(c, hipMalloc(&c->rho, cap * sizeof(float)));
+        TC_HIP(c, hipMalloc(&c->vhf, cap * sizeof(float)));
+        if (tc_select_temp_bytes(cap, &c->sel_tmp_bytes)) TC_FAIL(c, TCGPU_ERR_HIP, "select temp query failed");
+        TC_HIP(c, hipMalloc(&c->sel_tmp, c->sel_tmp_bytes ? c->sel_tmp_bytes : 16));
         TC_HIP(c, hipMalloc(&c->key, cap * sizeof(tc_u128)));
         TC_HIP(c, hipMalloc(&c->key_sorted, cap * sizeof(tc_u128)));
         TC_HIP(c, hipMalloc(&c->idx, cap * sizeof(uint32_t)));
         TC_HIP(c, hipMalloc(&c->idx_sorted, cap * sizeof(uint32_t)));
         if (tc_sort_temp_bytes(cap, &c->sort_tmp_bytes)) TC_FAIL(c, TCGPU_ERR_HIP, "radix sort temp query failed");
         TC_HIP(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
-        TC_HIP(c, hipMalloc(&c->guess, cap * sizeof(float)));
+        TC_HIP(c, hipMalloc(&c->guess, 3 * cap * sizeof(float)));     /* also 3 floats/particle of scratch (presentation) */
         TC_HIP(c, hipMalloc(&c->hwvt, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->delta, 3 * cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->ustep, 3 * cap * sizeof(double)));
         TC_HIP(c, hipMalloc(&c->rhom_next, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->stats, 4 * cap * sizeof(uint32_t)));
         TC_HIP(c, hipMalloc(&c->ngb_buf, cap * sizeof(int32_t)));
+        TC_HIP(c, hipMemset(c->hwvt, 0, cap * sizeof(float)));
+        TC_HIP(c, hipMemset(c->delta, 0, 3 * cap * sizeof(float)));
+        TC_HIP(c, hipMemset(c->rhom_next, 0, cap * sizeof(float)));
         c->cap = need;
     }
     int lmax = c->lmax_override > 0 ? c->lmax_override : pick_lmax(n);
@@ -237,6 +275,7 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         c->ncells_alloc = ncell;
     }
     c->lmax = lmax;
+    c->lp_max = lmax < TC_LP_MAX ? lmax : TC_LP_MAX;
     /* row-major mirror: every level whose scan (12 B per cell) is cheap next to the per-particle saving;
      * queries at a deeper level use the cell-by-cell path */
     int lmax_rm = lmax;
@@ -250,6 +289,8 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
                         "row-run fast path disabled (cell-by-cell path only)\n", (long long)n, lmax_rm - lmin_rm + 1);
         lmax_rm = 0;
     }
+    c->lmax_rm0 = lmax_rm;
+    c->lmin_rm0 = lmin_rm;
     c->lmax_rm = lmax_rm;
     c->lmin_rm = lmin_rm;
     c->mirror_valid = 0;
@@ -298,7 +339,7 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
     int rc = ensure_capacity(c, n);
     if (rc) return rc;
     c->n = n;
-    c->cur = 0;
+    c->gcur = 0;
     set_shard(c);
     size_t cap = (size_t)c->cap;
     /* pack xyz -> float4 on the host (w = 0) */
@@ -310,20 +351,25 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
         tid[i] = id ? id[i] : (int32_t)(i + 1);
     }
     for (size_t i = n; i < cap; i++) { tmp[i] = make_float4(0, 0, 0, 0); tid[i] = 0; }
-    hipError_t e1 = hipMemcpyAsync(c->pos4[0], tmp, cap * sizeof(float4), hipMemcpyHostToDevice, c->stream);
-    hipError_t e2 = hipMemcpyAsync(c->id[0], tid, cap * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    hipError_t e1 = hipMemcpyAsync(c->g_pos4[0], tmp, cap * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    hipError_t e2 = hipMemcpyAsync(c->g_id[0], tid, cap * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     hipError_t e3 = hipStreamSynchronize(c->stream);
     free(tmp); free(tid);
     TC_HIP(c, e1); TC_HIP(c, e2); TC_HIP(c, e3);
-    TC_HIP(c, hipMemsetAsync(c->hsml[0], 0, cap * sizeof(float), c->stream));
-    if (hsml) TC_HIP(c, hipMemcpyAsync(c->hsml[0], hsml, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    TC_HIP(c, hipMemsetAsync(c->rho[0], 0, cap * sizeof(float), c->stream));
-    TC_HIP(c, hipMemsetAsync(c->vhf[0], 0, cap * sizeof(float), c->stream));
-    TC_HIP(c, hipMemsetAsync(c->rhom[0], 0, cap * sizeof(float), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->g_hsml[0], 0, cap * sizeof(float), c->stream));
+    if (hsml) TC_HIP(c, hipMemcpyAsync(c->g_hsml[0], hsml, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    TC_HIP(c, hipMemsetAsync(c->g_rho[0], 0, cap * sizeof(float), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->g_vhf[0], 0, cap * sizeof(float), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->g_rhom[0], 0, cap * sizeof(float), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->g_key, 0, cap * sizeof(tc_u128), c->stream));
     TC_HIP(c, hipStreamSynchronize(c->stream));
     c->keys_valid = 0;
     c->index_valid = 0; c->mirror_valid = 0;
     c->ustep_valid = 0;
+    c->order_dirty = 0;
+    c->g_compact = 0;
+    c->w_valid = 0;
+    c->nloc = 0; c->nown = 0; c->local_full = 0;
     c->need_guess = 1;
     if (hsml) {                                   /* warm start: the guess is only read where hsml == 0 */
         c->need_guess = 0;
@@ -333,34 +379,11 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
     return TCGPU_OK;
 }
 
-extern "C" int tcgpu_download_particles(tcgpu_ctx *c, float *pos, int32_t *id, float *hsml, float *rho, float *vhf,
-                                        float *rhom)
-{
-    if (!c || c->n <= 0) return TCGPU_ERR_ARG;
-    TC_HIP(c, hipSetDevice(c->device));
-    TC_HIP(c, hipStreamSynchronize(c->stream));
-    size_t n = (size_t)c->n;
-    int b = c->cur;
-    if (pos) {
-        float4 *tmp = (float4 *)malloc(n * sizeof(float4));
-        if (!tmp) return TCGPU_ERR_NOMEM;
-        hipError_t e = hipMemcpy(tmp, c->pos4[b], n * sizeof(float4), hipMemcpyDeviceToHost);
-        if (e == hipSuccess)
-            for (size_t i = 0; i < n; i++) { pos[3 * i] = tmp[i].x; pos[3 * i + 1] = tmp[i].y; pos[3 * i + 2] = tmp[i].z; }
-        free(tmp);
-        TC_HIP(c, e);
-    }
-    if (id) TC_HIP(c, hipMemcpy(id, c->id[b], n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (hsml) TC_HIP(c, hipMemcpy(hsml, c->hsml[b], n * sizeof(float), hipMemcpyDeviceToHost));
-    if (rho) TC_HIP(c, hipMemcpy(rho, c->rho[b], n * sizeof(float), hipMemcpyDeviceToHost));
-    if (vhf) TC_HIP(c, hipMemcpy(vhf, c->vhf[b], n * sizeof(float), hipMemcpyDeviceToHost));
-    if (rhom) TC_HIP(c, hipMemcpy(rhom, c->rhom[b], n * sizeof(float), hipMemcpyDeviceToHost));
-    return TCGPU_OK;
-}
-
 /* ------------------------------------------------------------------ flags */
 
-/* `reduced`: the four error flags already maximised over the ranks (multi-rank contexts: every rank must take
+#define TC_RETRY_FULL 1000      /* internal: a query left the ghost margin, repeat the pass on the full set */
+
+/* `reduced`: the five flags already maximised over the ranks (multi-rank contexts: every rank must take
  * the same exit, or the ranks that carry on would wait forever in the next collective); NULL = this rank's own. */
 static int check_flags(tcgpu_ctx *c, const double *reduced = nullptr)
 {
@@ -369,12 +392,19 @@ static int check_flags(tcgpu_ctx *c, const double *reduced = nullptr)
     tc_phase_collect(c);
     int f[8];
     memcpy(f, c->h_flags, sizeof(f));
-    if (f[0] || f[1] || f[2] || f[3]) TC_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
-    if (reduced)
+    if (f[0] || f[1] || f[2] || f[3] || f[5]) {
+        TC_HIP(c, hipMemsetAsync(c->flags, 0, sizeof(int) * 4, c->stream));
+        TC_HIP(c, hipMemsetAsync(c->flags + 5, 0, sizeof(int), c->stream));
+    }
+    int margin = f[5] != 0;
+    if (reduced) {
         for (int q = 0; q < 4; q++) f[q] = reduced[q] != 0;
+        margin = reduced[4] != 0;
+    }
     if (f[1]) TC_FAIL(c, TCGPU_ERR_COORD_RANGE, "coordinate outside [0,boxsize] (reference: peano.c:130-132 Assert)");
     if (f[0]) TC_FAIL(c, TCGPU_ERR_NONFINITE, "hsml not finite (reference: sph.c:28 Assert)");
     if (f[3]) TC_FAIL(c, TCGPU_ERR_OVERFLOW, "more than %d particles sit exactly on the upper box face", TC_MAX_ORPHANS);
+    if (margin) return TC_RETRY_FULL;
     if (f[2]) TC_FAIL(c, TCGPU_ERR_NO_CONVERGENCE, "hsml iteration did not terminate for some particle");
     return TCGPU_OK;
 }
@@ -435,10 +465,11 @@ extern "C" int tcgpu_comm_init(tcgpu_ctx *c, int rank, int nranks, const uint8_t
     return TCGPU_OK;
 }
 
-/* In-place all-gather of one shard-partitioned array (elements of `esize` bytes). */
+/* In-place all-gather of one shard-partitioned array of G (elements of `esize` bytes). */
 static int allgather_inplace(tcgpu_ctx *c, void *base, size_t esize)
 {
     size_t bytes = (size_t)c->shard_len * esize;
+    c->comm_bytes += (double)bytes * (c->nranks - 1);                 /* received per rank */
     if (c->loop) {
         tc_loop_comm *L = c->loop;
         TC_HIP(c, hipStreamSynchronize(c->stream));
@@ -459,51 +490,54 @@ static int allgather_inplace(tcgpu_ctx *c, void *base, size_t esize)
     return 0;
 }
 
-/* all-reduce of the scalars of one pass, in place on the device: buf[0..2] summed (error sum, particle count,
- * spare), buf[3..7] maximised (largest error and the four error flags as 0/1, see check_flags) */
-static int allreduce_pass_scalars(tcgpu_ctx *c, double *buf)
+/* all-reduce, in place on the device: buf[0..nsum) summed, buf[nsum..nsum+nmax) maximised.  All summed values
+ * are integers below 2^53 held in doubles (exact limbs, counts), so the result is exact and order-independent. */
+static int allreduce_scalars(tcgpu_ctx *c, double *buf, int nsum, int nmax)
 {
+    const int nt = nsum + nmax;
     if (c->loop) {
         tc_loop_comm *L = c->loop;
-        double h[8];
-        TC_HIP(c, hipMemcpyAsync(h, buf, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        double h[16];
+        TC_HIP(c, hipMemcpyAsync(h, buf, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         TC_HIP(c, hipStreamSynchronize(c->stream));
-        memcpy(L->red[c->rank], h, sizeof(h));
+        memcpy(L->red[c->rank], h, nt * sizeof(double));
         pthread_barrier_wait(&L->bar);
-        double o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double o[16] = {0};
         for (int p = 0; p < L->nranks; p++) {
-            for (int q = 0; q < 3; q++) o[q] += L->red[p][q];
-            for (int q = 3; q < 8; q++) o[q] = fmax(o[q], L->red[p][q]);
+            for (int q = 0; q < nsum; q++) o[q] += L->red[p][q];
+            for (int q = nsum; q < nt; q++) o[q] = fmax(o[q], L->red[p][q]);
         }
         pthread_barrier_wait(&L->bar);
-        TC_HIP(c, hipMemcpyAsync(buf, o, sizeof(o), hipMemcpyHostToDevice, c->stream));
+        TC_HIP(c, hipMemcpyAsync(buf, o, nt * sizeof(double), hipMemcpyHostToDevice, c->stream));
         TC_HIP(c, hipStreamSynchronize(c->stream));
         return 0;
     }
     g_rccl.GroupStart();
-    ncclResult_t r1 = g_rccl.AllReduce(buf, buf, 3, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
-    ncclResult_t r2 = g_rccl.AllReduce(buf + 3, buf + 3, 5, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream);
+    ncclResult_t r1 = ncclSuccess, r2 = ncclSuccess;
+    if (nsum > 0) r1 = g_rccl.AllReduce(buf, buf, nsum, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream);
+    if (nmax > 0) r2 = g_rccl.AllReduce(buf + nsum, buf + nsum, nmax, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream);
     ncclResult_t r3 = g_rccl.GroupEnd();
     if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess) TC_FAIL(c, TCGPU_ERR_COMM, "ncclAllReduce failed");
     return 0;
 }
 
+static inline bool multi(const tcgpu_ctx *c) { return c->comm || c->loop; }
+
 /* multi-rank contexts: agree on the error flags (maximum over the ranks), then check them; every rank
  * returns the same status.  Single rank: the plain check. */
 static int check_flags_collective(tcgpu_ctx *c)
 {
-    if (!(c->comm || c->loop)) return check_flags(c);
-    double *buf = c->red + 4 * TC_RED_BLOCKS + 8;
-    TC_HIP(c, hipMemsetAsync(buf, 0, 8 * sizeof(double), c->stream));
-    int rc = tc_launch_flags_to_f64(c, buf + 4);
+    if (!multi(c)) return check_flags(c);
+    double *buf = tc_pass_scalars(c) + 32;
+    int rc = tc_launch_flags_to_f64(c, buf);
     if (rc) return rc;
     tc_phase_begin(c, PH_COMM);
-    rc = allreduce_pass_scalars(c, buf);
+    rc = allreduce_scalars(c, buf, 0, TC_PS_FLAGS);
     tc_phase_end(c);
     if (rc) return rc;
-    TC_HIP(c, hipMemcpyAsync(c->h_red + 8, buf, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TC_HIP(c, hipMemcpyAsync(c->h_red + 32, buf, TC_PS_FLAGS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     TC_HIP(c, hipStreamSynchronize(c->stream));
-    return check_flags(c, c->h_red + 8 + 4);
+    return check_flags(c, c->h_red + 32);
 }
 
 /* testing: tie `nranks` contexts of this process into a loopback communicator (one thread each) */
@@ -523,39 +557,181 @@ extern "C" int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks)
     return TCGPU_OK;
 }
 
-/* ------------------------------------------------------------------ sort / index */
+/* ------------------------------------------------------------------ presentation: G <- Peano order */
 
-extern "C" int tcgpu_sort_particles_by_peano_key(tcgpu_ctx *c)
+/* Bring the global arrays into the Peano order of the last density pass -- the order the reference leaves P and
+ * SphP in (src/peano.c:85-126) -- completing the per-particle state on every rank first.  Called lazily by
+ * everything that shows or takes per-particle arrays; inside the relaxation loop nothing needs it.  It is also
+ * what makes the index ranges of G spatially compact shards (g_compact). */
+static int present(tcgpu_ctx *c)
 {
-    if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
-    TC_HIP(c, hipSetDevice(c->device));
+    if (!c->order_dirty) return 0;
+    int rc = 0;
+    const int b = c->gcur;
+    tc_phase_begin(c, PH_PRESENT);
+    if (multi(c)) {
+        if (c->comm) g_rccl.GroupStart();
+        rc = allgather_inplace(c, c->g_hsml[b], sizeof(float));
+        if (!rc) rc = allgather_inplace(c, c->g_rho[b], sizeof(float));
+        if (!rc) rc = allgather_inplace(c, c->g_vhf[b], sizeof(float));
+        if (!rc) rc = allgather_inplace(c, c->g_rhom[b], sizeof(float));
+        if (!rc) rc = allgather_inplace(c, c->g_key, sizeof(tc_u128));
+        if (c->comm && g_rccl.GroupEnd() != ncclSuccess && !rc) {
+            snprintf(c->err, sizeof(c->err), "ncclGroupEnd failed");
+            rc = TCGPU_ERR_COMM;
+        }
+        if (rc) { tc_phase_end(c); return rc; }
+    }
+    if ((rc = tc_launch_iota(c, c->idx, (size_t)c->n, 0))) return rc;
+    int sort_levels = c->lmax + 5;
+    if (sort_levels > 21) sort_levels = 21;
+    if (tc_sort_pairs_u128(c->sort_tmp, c->sort_tmp_bytes, c->g_key, c->g_key_sorted, c->idx, c->idx_sorted, (size_t)c->n,
+                           3 * sort_levels + 1, c->stream)) {
+        tc_phase_end(c);
+        TC_FAIL(c, TCGPU_ERR_HIP, "radix sort failed");
+    }
+    if ((rc = tc_launch_present_permute(c, c->idx_sorted))) return rc;
+    TC_HIP(c, hipMemcpyAsync(c->g_key, c->g_key_sorted, (size_t)c->n * sizeof(tc_u128), hipMemcpyDeviceToDevice, c->stream));
+    c->order_dirty = 0;
+    c->keys_valid = 1;
+    c->g_compact = 1;
+    if (c->local_full && c->index_valid) {
+        /* a full local set is sorted by the same keys with the same tie rule: local slot i IS presented index i */
+        int64_t lo, hi;
+        tc_own_range(c, &lo, &hi);
+        if ((rc = tc_launch_iota(c, c->lg, (size_t)c->n, 0))) return rc;
+        if (multi(c) && (rc = tc_launch_iota(c, c->own_list, (size_t)(hi - lo), (uint32_t)lo))) return rc;
+        c->nown = hi - lo;
+    } else {
+        c->index_valid = 0; c->mirror_valid = 0; c->ustep_valid = 0;
+    }
+    if (multi(c)) c->w_valid = 0;                 /* hwvt / rhom_next are own-range arrays: the ranges just changed */
+    tc_phase_end(c);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ model hsml of the current positions */
+
+/* src/wvt_relax.c:108-124 for the own range, normalised with the sum over ALL particles (exact, all-reduced);
+ * the result rides in g_pos4.w, so sharded contexts complete positions and w with ONE all-gather. */
+static int ensure_w(tcgpu_ctx *c)
+{
+    if (c->w_valid) return 0;
     int rc;
-    if ((rc = tc_launch_keys(c))) return rc;
+    if ((rc = tc_launch_model_hsml_own(c))) return rc;
+    if (multi(c)) {
+        tc_phase_begin(c, PH_COMM);
+        rc = allreduce_scalars(c, tc_pass_scalars(c) + TC_PS_H3, 3, 0);
+        tc_phase_end(c);
+        if (rc) return rc;
+    }
+    if ((rc = tc_launch_scale_hsml_own(c))) return rc;
+    if (multi(c)) {
+        tc_phase_begin(c, PH_COMM);
+        rc = allgather_inplace(c, c->g_pos4[c->gcur], sizeof(float4));
+        tc_phase_end(c);
+        if (rc) return rc;
+    }
+    c->w_valid = 1;
+    c->local_w_valid = 0;                         /* the local copy of the w lane (if any) predates it */
+    c->mirror_valid = 0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ local set + neighbour index */
+
+/* K1-K4 of one pass: choose the local set (everything if `full`), key and sort it (src/peano.c:46-126), gather
+ * it into sorted order, build the cell table (replaces src/tree.c:124-271). */
+static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
+{
+    int rc;
+    c->index_valid = 0; c->mirror_valid = 0; c->ustep_valid = 0;
+    if (!multi(c)) full = 1;
+    if (full) {
+        c->local_full = 1;
+        c->nloc = c->n;
+        c->lmin_tab = 1;
+    } else {
+        tc_phase_begin(c, PH_LOCAL);
+        rc = tc_launch_mark_interest(c);
+        tc_phase_end(c);
+        if (rc) return rc;
+        int64_t nloc = 0;
+        if ((rc = tc_select_local(c, &nloc))) return rc;              /* synchronises: the launch sizes below need nloc */
+        c->local_full = 0;
+        c->nloc = nloc;
+    }
+    c->lmax_rm = c->lmax_rm0;
+    c->lmin_rm = c->lmin_rm0 > c->lmin_tab ? c->lmin_rm0 : c->lmin_tab;
+    if (c->lmin_rm > c->lmax_rm) c->lmax_rm = 0;
+    if ((rc = tc_launch_keys_local(c))) return rc;
     tc_phase_begin(c, PH_SORT);
     /* large sets: radix passes only over the Hilbert levels that separate particles in practice, five below
      * the deepest cell-table level (3 bits per level); the fix-up orders whatever still ties, exactly */
     int sort_levels = c->lmax + 5;
     if (sort_levels > 21) sort_levels = 21;
     int s = tc_sort_pairs_u128(c->sort_tmp, c->sort_tmp_bytes, c->key, c->key_sorted, c->idx, c->idx_sorted,
-                               (size_t)c->n, 3 * sort_levels + 1, c->stream);
+                               (size_t)c->nloc, 3 * sort_levels + 1, c->stream);
     tc_phase_end(c);
     if (s) TC_FAIL(c, TCGPU_ERR_HIP, "radix sort failed");
-    if ((rc = tc_launch_permute(c))) return rc;
-    c->keys_valid = 1;
-    c->index_valid = 0; c->mirror_valid = 0;
-    c->ustep_valid = 0;
+    if ((rc = tc_launch_gather_local(c))) return rc;
+    c->local_w_valid = c->w_valid;
+    if (mark_dirty) { c->order_dirty = 1; c->keys_valid = 0; }
+    if (with_cells && (rc = tc_launch_cells(c))) return rc;
+    return 0;
+}
+
+extern "C" int tcgpu_sort_particles_by_peano_key(tcgpu_ctx *c)
+{
+    if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
+    TC_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = present(c))) return rc;                           /* state of earlier passes first */
+    if ((rc = build_local(c, 1, 0, 1))) return rc;
+    c->index_valid = 0;
+    return present(c);
+}
+
+extern "C" int tcgpu_download_particles(tcgpu_ctx *c, float *pos, int32_t *id, float *hsml, float *rho, float *vhf,
+                                        float *rhom)
+{
+    if (!c || c->n <= 0) return TCGPU_ERR_ARG;
+    TC_HIP(c, hipSetDevice(c->device));
+    int rc = present(c);
+    if (rc) return rc;
+    TC_HIP(c, hipStreamSynchronize(c->stream));
+    tc_phase_collect(c);
+    size_t n = (size_t)c->n;
+    int b = c->gcur;
+    if (pos) {
+        float4 *tmp = (float4 *)malloc(n * sizeof(float4));
+        if (!tmp) return TCGPU_ERR_NOMEM;
+        hipError_t e = hipMemcpy(tmp, c->g_pos4[b], n * sizeof(float4), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (size_t i = 0; i < n; i++) { pos[3 * i] = tmp[i].x; pos[3 * i + 1] = tmp[i].y; pos[3 * i + 2] = tmp[i].z; }
+        free(tmp);
+        TC_HIP(c, e);
+    }
+    if (id) TC_HIP(c, hipMemcpy(id, c->g_id[b], n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (hsml) TC_HIP(c, hipMemcpy(hsml, c->g_hsml[b], n * sizeof(float), hipMemcpyDeviceToHost));
+    if (rho) TC_HIP(c, hipMemcpy(rho, c->g_rho[b], n * sizeof(float), hipMemcpyDeviceToHost));
+    if (vhf) TC_HIP(c, hipMemcpy(vhf, c->g_vhf[b], n * sizeof(float), hipMemcpyDeviceToHost));
+    if (rhom) TC_HIP(c, hipMemcpy(rhom, c->g_rhom[b], n * sizeof(float), hipMemcpyDeviceToHost));
     return TCGPU_OK;
 }
 
 extern "C" int tcgpu_download_keys(tcgpu_ctx *c, uint64_t *hi, uint64_t *lo)
 {
-    if (!c || c->n <= 0 || !c->keys_valid) return TCGPU_ERR_ARG;
+    if (!c || c->n <= 0) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
+    int rc = present(c);
+    if (rc) return rc;
+    if (!c->keys_valid) TC_FAIL(c, TCGPU_ERR_ARG, "no keys yet (call tcgpu_sort_particles_by_peano_key or a density pass first)");
     TC_HIP(c, hipStreamSynchronize(c->stream));
     size_t n = (size_t)c->n;
     tc_u128 *t = (tc_u128 *)malloc(n * sizeof(tc_u128));
     if (!t) return TCGPU_ERR_NOMEM;
-    hipError_t e = hipMemcpy(t, c->key_sorted, n * sizeof(tc_u128), hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(t, c->g_key_sorted, n * sizeof(tc_u128), hipMemcpyDeviceToHost);
     if (e == hipSuccess)
         for (size_t i = 0; i < n; i++) {
             if (hi) hi[i] = (uint64_t)(t[i] >> 64);
@@ -563,7 +739,8 @@ extern "C" int tcgpu_download_keys(tcgpu_ctx *c, uint64_t *hi, uint64_t *lo)
         }
     free(t);
     TC_HIP(c, e);
-    return check_flags(c);
+    rc = check_flags(c);
+    return rc == TC_RETRY_FULL ? TCGPU_OK : rc;
 }
 
 extern "C" int tcgpu_peano_keys(tcgpu_ctx *c, int64_t n, const double *xyz, uint64_t *hi, uint64_t *lo)
@@ -585,86 +762,85 @@ extern "C" int tcgpu_peano_keys(tcgpu_ctx *c, int64_t n, const double *xyz, uint
     return rc;
 }
 
+/* the whole set, sorted and indexed, in presented order: what tcgpu_find_ngb / tcgpu_guess_hsml address */
+static int full_index(tcgpu_ctx *c)
+{
+    int rc;
+    if ((rc = present(c))) return rc;
+    if (c->index_valid && c->local_full) return 0;
+    if ((rc = build_local(c, 1, 1, 1))) return rc;
+    return present(c);
+}
+
 extern "C" int tcgpu_build_neighbour_index(tcgpu_ctx *c)
 {
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
-    int rc;
-    if (!c->keys_valid && (rc = tcgpu_sort_particles_by_peano_key(c))) return rc;
-    if ((rc = tc_launch_cells(c))) return rc;
-    return check_flags(c);
+    int rc = full_index(c);
+    if (rc) return rc;
+    rc = check_flags_collective(c);
+    return rc == TC_RETRY_FULL ? TCGPU_OK : rc;
 }
 
 /* ------------------------------------------------------------------ density pass */
 
 static int density_stats(tcgpu_ctx *c)
 {
-    size_t n = (size_t)c->n, cap = (size_t)c->cap;
+    size_t cap = (size_t)c->cap, nown = (size_t)c->nown;
     uint32_t *h = (uint32_t *)malloc(4 * cap * sizeof(uint32_t));
-    if (!h) return TCGPU_ERR_NOMEM;
+    uint32_t *own = (uint32_t *)malloc((nown ? nown : 1) * sizeof(uint32_t));
+    if (!h || !own) { free(h); free(own); return TCGPU_ERR_NOMEM; }
     hipError_t e = hipMemcpy(h, c->stats, 4 * cap * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && c->nranks > 1) e = hipMemcpy(own, c->own_list, nown * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
-        int64_t lo = c->rank * c->shard_len, hi = std::min<int64_t>((c->rank + 1) * c->shard_len, (int64_t)n);
         double s[4] = {0, 0, 0, 0};
         for (int q = 0; q < 4; q++)
-            for (int64_t i = lo; i < hi; i++) s[q] += h[q * cap + i];
-        double m = (double)std::max<int64_t>(1, hi - lo);
+            for (size_t t = 0; t < nown; t++) s[q] += h[q * cap + (c->nranks > 1 ? own[t] : t)];
+        double m = (double)(nown ? nown : 1);
         c->last_stats.queries_per_particle = s[0] / m;
         c->last_stats.solver_iters_per_particle = s[1] / m;
         c->last_stats.pair_evals_per_particle = s[2] / m;
         c->last_stats.candidates_per_particle = s[3] / m;
     }
-    free(h);
+    free(h); free(own);
     TC_HIP(c, e);
     return 0;
 }
 
-/* gather_all: also all-gather rho and varHsmlFac (needed once results are read back; inside the
- * relaxation loop other ranks only need the carried hsml for their next warm start) */
-static int gather_sph(tcgpu_ctx *c, int gather_all)
-{
-    if (!(c->comm || c->loop)) return 0;
-    tc_phase_begin(c, PH_COMM);
-    if (c->comm) g_rccl.GroupStart();
-    int r1 = allgather_inplace(c, c->hsml[c->cur], sizeof(float)), r2 = 0, r3 = 0;
-    if (gather_all && !r1) {
-        r2 = allgather_inplace(c, c->rho[c->cur], sizeof(float));
-        if (!r2) r3 = allgather_inplace(c, c->vhf[c->cur], sizeof(float));
-    }
-    /* the group is closed whatever happened in it */
-    if (c->comm && g_rccl.GroupEnd() != ncclSuccess && !(r1 || r2 || r3)) {
-        snprintf(c->err, sizeof(c->err), "ncclGroupEnd failed");
-        r1 = TCGPU_ERR_COMM;
-    }
-    tc_phase_end(c);
-    return (r1 || r2 || r3) ? TCGPU_ERR_COMM : 0;
-}
-
-static int find_sph_quantities_nocheck(tcgpu_ctx *c, int need_guess, int with_wvt, int gather_all)
+/* One density pass (src/sph.c:13-72) up to, not including, the write-back of the results: local set, sort, index,
+ * first-pass guess, solve.  `full` forces the whole set as local set. */
+static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int full)
 {
     int rc;
-    if ((rc = tcgpu_sort_particles_by_peano_key(c))) return rc;
-    if ((rc = tc_launch_cells(c))) return rc;
+    /* first warm pass of a sharded context: G is still the upload order -- make the shards compact first */
+    if (multi(c) && !c->g_compact && c->order_dirty && !need_guess && (rc = present(c))) return rc;
+    if (with_wvt && (rc = ensure_w(c))) return rc;
+    if (need_guess || !c->g_compact) full = 1;
+    if ((rc = build_local(c, full, 1, 1))) return rc;
     if (need_guess && (rc = tc_launch_guess(c))) return rc;
     if (c->fuse) {
         /* one gather per particle serves the density solve and (with_wvt) the WVT sweep that
-         * follows on the same positions; the sweep needs the model hsml up front */
-        if (with_wvt && (rc = tc_launch_model_hsml(c))) return rc;
+         * follows on the same positions */
         if ((rc = tc_launch_mirror(c))) return rc;
         if ((rc = tc_launch_iter(c, with_wvt))) return rc;
         c->ustep_valid = with_wvt;
     } else if ((rc = tc_launch_density(c))) return rc;
-    return gather_sph(c, gather_all);
+    return 0;
 }
 
 extern "C" int tcgpu_find_sph_quantities(tcgpu_ctx *c)
 {
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
-    int rc = find_sph_quantities_nocheck(c, c->need_guess, 0, 1);
+    int rc, full = 0;
+    for (;;) {
+        if ((rc = density_pass_launch(c, c->need_guess, 0, full))) return rc;
+        rc = check_flags_collective(c);
+        if (rc != TC_RETRY_FULL) break;
+        full = 1; c->margin_retry++;              /* a query left the ghost margin: the same pass on the full set */
+    }
     if (rc) return rc;
-    rc = check_flags_collective(c);
-    if (rc) return rc;
+    if ((rc = tc_launch_scatter_results(c))) return rc;
     c->need_guess = 0;                            /* every hsml is > 0 after a successful pass */
     if (c->want_stats) return density_stats(c);
     return TCGPU_OK;
@@ -681,7 +857,9 @@ extern "C" int tcgpu_global_density_model(tcgpu_ctx *c, float *out)
 {
     if (!c || !out || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
-    int rc = tc_launch_model(c, c->guess);       /* guess doubles as f32 scratch */
+    int rc = present(c);
+    if (rc) return rc;
+    rc = tc_launch_model(c, c->guess);           /* guess doubles as f32 scratch */
     if (rc) return rc;
     TC_HIP(c, hipStreamSynchronize(c->stream));
     TC_HIP(c, hipMemcpy(out, c->guess, (size_t)c->n * sizeof(float), hipMemcpyDeviceToHost));
@@ -693,19 +871,25 @@ extern "C" int tcgpu_guess_hsml(tcgpu_ctx *c, float *out)
     if (!c || !out || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc;
-    if (!c->keys_valid && (rc = tcgpu_sort_particles_by_peano_key(c))) return rc;
+    if ((rc = present(c))) return rc;
+    if ((rc = build_local(c, 1, 0, 1))) return rc;            /* keys of the whole set, sorted: the guess reads the tree */
+    if ((rc = present(c))) return rc;
     if ((rc = tc_launch_guess(c))) return rc;
     TC_HIP(c, hipStreamSynchronize(c->stream));
     TC_HIP(c, hipMemcpy(out, c->guess, (size_t)c->n * sizeof(float), hipMemcpyDeviceToHost));
-    return check_flags(c);
+    rc = check_flags(c);
+    return rc == TC_RETRY_FULL ? TCGPU_OK : rc;
 }
 
 extern "C" int tcgpu_find_ngb(tcgpu_ctx *c, int64_t ipart, float hsml, int32_t *list, int32_t *count)
 {
     if (!c || !list || !count || ipart < 0 || ipart >= c->n) return TCGPU_ERR_ARG;
-    if (!c->index_valid) TC_FAIL(c, TCGPU_ERR_ARG, "neighbour index not built");
     TC_HIP(c, hipSetDevice(c->device));
-    int rc = tc_launch_find_ngb(c, (int)ipart, hsml);
+    int rc = present(c);
+    if (rc) return rc;
+    if (!c->index_valid || !c->local_full)
+        TC_FAIL(c, TCGPU_ERR_ARG, "neighbour index over the whole set not built (call tcgpu_build_neighbour_index)");
+    rc = tc_launch_find_ngb(c, (int)ipart, hsml);
     if (rc) return rc;
     TC_HIP(c, hipStreamSynchronize(c->stream));
     int cnt = 0;
@@ -733,18 +917,21 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
         if ((rc = tc_launch_commit_rhom(c))) return rc;
         if ((rc = tc_launch_apply_step(c, step))) return rc;
     } else {
-        if ((rc = tc_launch_model_hsml(c))) return rc;
+        if ((rc = ensure_w(c))) return rc;
+        if (!c->index_valid) {                    /* e.g. a presentation dropped a sharded local set: rebuild it */
+            if ((rc = build_local(c, !c->g_compact, 1, 0))) return rc;
+        } else if (!c->local_w_valid) {           /* the model hsml was computed after the local gather */
+            if ((rc = tc_launch_refresh_w(c))) return rc;
+            c->local_w_valid = 1;
+        }
         if ((rc = tc_launch_commit_rhom(c))) return rc;
         if ((rc = tc_launch_wvt(c, step))) return rc;
     }
     if (move) {
         if ((rc = tc_launch_move(c))) return rc;
-        if (c->comm || c->loop) {
-            tc_phase_begin(c, PH_COMM);
-            rc = allgather_inplace(c, c->pos4[c->cur], sizeof(float4));
-            tc_phase_end(c);
-            if (rc) return rc;
-        }
+        /* sharded contexts complete the moved positions right away, together with the model hsml of the new
+         * positions (one all-gather of 16 B per particle and iteration) */
+        if (multi(c) && (rc = ensure_w(c))) return rc;
     }
     return 0;
 }
@@ -752,15 +939,25 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
 extern "C" int tcgpu_wvt_step(tcgpu_ctx *c, double step, float *hsml_wvt, float *delta, int move)
 {
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
-    if (!c->index_valid) TC_FAIL(c, TCGPU_ERR_ARG, "neighbour index not built (call tcgpu_find_sph_quantities first)");
+    if (c->need_guess) TC_FAIL(c, TCGPU_ERR_ARG, "no density pass yet (call tcgpu_find_sph_quantities first)");
+    if (multi(c) && (hsml_wvt || delta))
+        TC_FAIL(c, TCGPU_ERR_ARG, "hsml_wvt / delta outputs are own-range arrays: not available on sharded contexts");
     TC_HIP(c, hipSetDevice(c->device));
-    int rc = wvt_step_nocheck(c, step, move);
+    int rc = wvt_step_nocheck(c, step, 0);
     if (rc) return rc;
+    if (hsml_wvt || delta) {
+        if ((rc = present(c))) return rc;         /* outputs in the order the caller sees */
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        size_t n = (size_t)c->n;
+        if (hsml_wvt) TC_HIP(c, hipMemcpy(hsml_wvt, c->hwvt, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (delta) TC_HIP(c, hipMemcpy(delta, c->delta, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (move) {
+        if ((rc = tc_launch_move(c))) return rc;
+        if (multi(c) && (rc = ensure_w(c))) return rc;
+    }
     TC_HIP(c, hipStreamSynchronize(c->stream));
     tc_phase_collect(c);
-    size_t n = (size_t)c->n;
-    if (hsml_wvt) TC_HIP(c, hipMemcpy(hsml_wvt, c->hwvt, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (delta) TC_HIP(c, hipMemcpy(delta, c->delta, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     return TCGPU_OK;
 }
 
@@ -768,24 +965,34 @@ extern "C" int tcgpu_wvt_step(tcgpu_ctx *c, double step, float *hsml_wvt, float 
  * error sums K6.  Synchronises the stream (the caller needs errMean to decide the step). */
 static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, double *err_max)
 {
-    int rc;
-    if ((rc = find_sph_quantities_nocheck(c, need_guess, 1, 0))) return rc;
-    if ((rc = tc_launch_error(c))) return rc;
-    double *fin = c->red + 4 * TC_RED_BLOCKS;                 /* {sum err, count, 0, max err} */
-    const bool multi = c->comm || c->loop;
-    if (multi) {
-        /* the error flags ride along (fin[4..7], maximised): every rank sees the same flags and takes the
-         * same exit -- a rank that returned alone would leave the others waiting in the next collective */
-        if ((rc = tc_launch_flags_to_f64(c, fin + 4))) return rc;
-        tc_phase_begin(c, PH_COMM);
-        rc = allreduce_pass_scalars(c, fin);
-        tc_phase_end(c);
-        if (rc) return rc;
+    int rc, full = 0;
+    double *ps = tc_pass_scalars(c);
+    for (;;) {
+        if ((rc = density_pass_launch(c, need_guess, 1, full))) return rc;
+        /* the error sums need this pass's densities in G order; the carried hsml is written back only once the
+         * pass is known to be good (a repeated pass must start from the same hsml) */
+        if ((rc = tc_launch_scatter_rho(c))) return rc;
+        if ((rc = tc_launch_error(c))) return rc;
+        /* the error flags ride along (maximised): every rank sees the same flags and takes the same exit -- a
+         * rank that returned alone would leave the others waiting in the next collective */
+        if ((rc = tc_launch_flags_to_f64(c, ps + TC_PS_NSUM + 1))) return rc;
+        if (multi(c)) {
+            tc_phase_begin(c, PH_COMM);
+            rc = allreduce_scalars(c, ps, TC_PS_NSUM, TC_PS_NMAX);
+            tc_phase_end(c);
+            if (rc) return rc;
+        }
+        TC_HIP(c, hipMemcpyAsync(c->h_red, ps, (TC_PS_NSUM + TC_PS_NMAX) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        rc = check_flags(c, multi(c) ? c->h_red + TC_PS_NSUM + 1 : nullptr);      /* synchronises the stream */
+        if (rc != TC_RETRY_FULL) break;
+        full = 1; c->margin_retry++;
     }
-    TC_HIP(c, hipMemcpyAsync(c->h_red, fin, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if ((rc = check_flags(c, multi ? c->h_red + 4 : nullptr))) return rc;      /* synchronises the stream */
-    *err_mean = c->h_red[0] / c->h_red[1];                    /* wvt_relax.c:87 */
-    *err_max = c->h_red[3];
+    if (rc) return rc;
+    if ((rc = tc_launch_scatter_results(c))) return rc;
+    /* exact sum -> f64 once, the same on every rank and for every split of the particles (wvt_relax.c:87) */
+    const double sum = tc_limbs_to_double(c->h_red[0], c->h_red[1], c->h_red[2], 1.0 / TC_ERR_SCALE);
+    *err_mean = sum / c->h_red[3];
+    *err_max = c->h_red[4];
     return 0;
 }
 
@@ -834,7 +1041,6 @@ extern "C" int tcgpu_regularise_sph_particles(tcgpu_ctx *c, int max_iter, tcgpu_
 
         if ((rc = wvt_step_nocheck(c, step, 1))) return rc;
     }
-    if ((rc = gather_sph(c, 1))) return rc;                   /* rho / varHsmlFac of the last pass, all ranks */
     TC_HIP(c, hipStreamSynchronize(c->stream));
     tc_phase_collect(c);
     if (nlog_out) *nlog_out = nlog;
@@ -847,18 +1053,26 @@ extern "C" int tcgpu_regularise_sph_particles(tcgpu_ctx *c, int max_iter, tcgpu_
 extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *bfld)
 {
     if (!c || !apot || !bfld || c->n <= 0) return TCGPU_ERR_ARG;
-    if (!c->index_valid) TC_FAIL(c, TCGPU_ERR_ARG, "neighbour index not built (call tcgpu_find_sph_quantities first)");
     TC_HIP(c, hipSetDevice(c->device));
+    int rc = present(c);                          /* `apot` is in the order the caller sees */
+    if (rc) return rc;
     size_t cap = (size_t)c->cap, n = (size_t)c->n;
     if (!c->apot) {
         TC_HIP(c, hipMalloc(&c->apot, 3 * cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->bfld, 3 * cap * sizeof(float)));
+        TC_HIP(c, hipMalloc(&c->l_apot, 6 * cap * sizeof(float)));          /* A and B in local order */
     }
+    float *l_bfld = c->l_apot + 3 * cap;
     TC_HIP(c, hipMemcpyAsync(c->apot, apot, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     TC_HIP(c, hipStreamSynchronize(c->stream));
-    int rc = tc_launch_curl(c);
-    if (rc) return rc;
-    if (c->comm || c->loop) {
+    /* the reference uses the tree of the preceding Find_sph_quantities() (src/main.c:54-56); a sharded local set
+     * does not survive the presentation, so it is rebuilt here from the converged smoothing lengths */
+    if (!c->index_valid && (rc = build_local(c, !c->g_compact, 1, 0))) return rc;
+    if ((rc = tc_launch_gather_rho_vhf(c))) return rc;
+    if ((rc = tc_launch_gather_apot(c))) return rc;
+    if ((rc = tc_launch_curl(c, l_bfld))) return rc;
+    if ((rc = tc_launch_scatter_bfld(c, l_bfld))) return rc;
+    if (multi(c)) {
         tc_phase_begin(c, PH_COMM);
         rc = allgather_inplace(c, c->bfld, 3 * sizeof(float));
         tc_phase_end(c);
@@ -881,7 +1095,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "level_scale")) c->level_scale = value > 0 ? value : 1.0;
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
-    else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = 0; }
+    else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = c->lmax_rm0 = 0; }
     else if (!strcmp(name, "force_comm")) c->force_comm = value != 0;   /* tests: 1-rank RCCL communicator */
     else if (!strcmp(name, "lmax")) {
         if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "lmax must be set before tcgpu_upload_particles");
@@ -904,5 +1118,24 @@ extern "C" int tcgpu_phase_times(tcgpu_ctx *c, const char **names, double *secon
     }
     *n = m;
     if (reset) { memset(c->ph_sec, 0, sizeof(c->ph_sec)); memset(c->ph_launch, 0, sizeof(c->ph_launch)); }
+    return TCGPU_OK;
+}
+
+/* bytes this rank has received in collectives since the last reset (sharded contexts; 0 on a single rank) */
+extern "C" double tcgpu_comm_bytes(tcgpu_ctx *c, int reset)
+{
+    if (!c) return 0;
+    const double b = c->comm_bytes;
+    if (reset) c->comm_bytes = 0;
+    return b;
+}
+
+/* size of the last local set, of the own range, and passes repeated on the full set so far */
+extern "C" int tcgpu_local_set_info(tcgpu_ctx *c, int64_t *nloc, int64_t *nown, int32_t *retries)
+{
+    if (!c) return TCGPU_ERR_ARG;
+    if (nloc) *nloc = c->nloc;
+    if (nown) *nown = c->nown;
+    if (retries) *retries = c->margin_retry;
     return TCGPU_OK;
 }

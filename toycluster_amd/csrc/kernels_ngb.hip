@@ -188,21 +188,10 @@ struct tc_query {
     size_t off;           /* table offset of the level */
 };
 
-/* table level of a query of radius h: floor(log2(box/h)) + 1 + level_shift, clamped to [1, lmax].
- * floor(log2(box/h)) from the exponents and mantissas of the two numbers (no division). */
+/* table level of a query of radius h (tc_query_level, tc_ctx.h), clamped to the levels this pass built */
 __device__ __forceinline__ int query_level(const tc_dev_const &k, float h)
 {
-    const double hd = (double)h * k.level_scale;
-    int L = 1;
-    if (hd <= k.boxsize) {
-        const int eh = __builtin_amdgcn_frexp_exp(hd) - 1;                 /* hd = mh * 2^eh, mh in [1, 2) */
-        const double mh = 2 * __builtin_amdgcn_frexp_mant(hd);
-        L = k.box_exp - eh - (k.box_mant < mh ? 1 : 0) + 1;
-    }
-    L += k.level_shift;
-    if (L < 1) L = 1;
-    if (L > k.lmax) L = k.lmax;
-    return L;
+    return tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmin_tab, k.lmax, h);
 }
 
 __device__ __forceinline__ double query_cell_edge_at(const tc_dev_const &k, int L)
@@ -575,7 +564,7 @@ __device__ __forceinline__ void work_queue(const tc_dev_const &k, F &&f)
             if (got >= (uint32_t)(gend - gstart)) break;
             const int base = gstart + (int)got;
             const int stop = base + TC_WORK_CHUNK < gend ? base + TC_WORK_CHUNK : gend;
-            for (int i = base; i < stop; i++) f(i);
+            for (int t = base; t < stop; t++) f(k.own ? (int)U(k.own[t]) : t);
         }
     }
 }
@@ -760,12 +749,19 @@ struct tc_dstate {
 /* src/sph.c:36-64 from the hsml in `d` on: ball query, raw-count guards, Find_hsml, until done */
 __device__ __forceinline__ void density_loop(const tc_density_args &a, int i, float xi, float yi, float zi,
                                              const tc_rlist &rl, uint32_t *idx, uint32_t idxcap, const tc_stage &st,
-                                             tc_dstate &d)
+                                             tc_dstate &d, float rmax)
 {
     const tc_dev_const &k = a.k;
     const int lane = lane_id();
     float hsml = d.hsml;
     for (int guard = 0; guard < 4096; guard++) {
+        /* sharded contexts: the ghost shell ends at rmax (tc_margin_radius); a wider query would miss neighbours.
+         * Flag it -- the host repeats the pass on the full set -- and leave the particle alone. */
+        if (hsml > rmax) {
+            if (lane == 0) atomicOr(&a.flags[5], 1);
+            d.ok = true;
+            break;
+        }
         /* ---- ball query (src/tree.c:25-111), f32 predicate, list capped at NGBMAX.
          * Hits (about a third of the candidates) are first compacted into a 128-entry LDS ring of
          * positions; the f64 pair distance is evaluated 64 hits at a time with every lane busy. */
@@ -852,7 +848,8 @@ __device__ __forceinline__ void density_one(const tc_density_args &a, int i, con
     const float4 pi = a.k.pos4[i];
     tc_dstate d;
     if (!density_init(a, i, d)) return;
-    density_loop(a, i, pi.x, pi.y, pi.z, rl, idx, TC_IDXCAP, st, d);
+    const float rmax = a.k.margin_on ? tc_margin_radius(a.hsml_in[i], pi.w, a.k.boxsize) : HUGE_VALF;
+    density_loop(a, i, pi.x, pi.y, pi.z, rl, idx, TC_IDXCAP, st, d, rmax);
     density_store(a, i, d);
 }
 
@@ -895,7 +892,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->cells = c->cells;
     k->orphans = c->orphans;
     k->norph = c->norph;
-    k->pos4 = c->pos4[c->cur];
+    k->pos4 = c->pos4;
     const bool rm = c->rows && c->mirror_valid && c->lmax_rm > 0;
     k->cum = rm ? tc_cum_base(c) : nullptr;
     k->mirror = rm ? c->mirror : nullptr;
@@ -903,12 +900,12 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->lmax_rm = rm ? c->lmax_rm : 0;
     k->lmin_rm = rm ? c->lmin_rm : 1;
     k->mirror_pad = (uint32_t)c->mirror_alloc;
-    k->n = (int)c->n;
-    int64_t lo = c->rank * c->shard_len, hi = (c->rank + 1) * c->shard_len;
-    if (hi > c->n) hi = c->n;
-    if (lo > hi) lo = hi;
-    k->lo = (int)lo;
-    k->hi = (int)hi;
+    k->n = (int)c->nloc;
+    k->lo = 0;
+    k->hi = (int)c->nown;
+    k->own = c->nranks > 1 ? c->own_list : nullptr;
+    k->lmin_tab = c->lmin_tab;
+    k->margin_on = !c->local_full;
     k->work_ctr = c->work_ctr;
     k->ablate = c->ablate;
 }
@@ -932,11 +929,11 @@ int tc_launch_density(tcgpu_ctx *c)
 {
     tc_density_args a;
     tc_fill_const(c, &a.k);
-    a.hsml_in = c->hsml[c->cur];
+    a.hsml_in = c->hsml;
     a.guess = c->guess;
-    a.hsml_out = c->hsml[c->cur];
-    a.rho_out = c->rho[c->cur];
-    a.vhf_out = c->vhf[c->cur];
+    a.hsml_out = c->hsml;
+    a.rho_out = c->rho;
+    a.vhf_out = c->vhf;
     a.bias_const = -0.0116 * pow(TC_DESNNGB * 0.01, -2.236);   /* src/sph.c:206 */
     a.spill = c->spill;
     a.flags = c->flags;
@@ -957,7 +954,8 @@ int tc_launch_density(tcgpu_ctx *c)
 struct tc_wvt_args {
     tc_dev_const k;
     double step;
-    float *delta;       /* 3n xyz interleaved */
+    float *delta;       /* 3n xyz interleaved, G order */
+    const uint32_t *lg; /* local slot -> G index */
     int *flags;
 };
 
@@ -1071,9 +1069,10 @@ __device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *i
     double d0, d1, d2;
     wvt_sum(a.k, i, pi, a.step * (double)pi.w, a.flags, idx, TC_IDXCAP, st, d0, d1, d2);
     if (lane_id() == 0) {
-        a.delta[3 * (size_t)i] = (float)d0;
-        a.delta[3 * (size_t)i + 1] = (float)d1;
-        a.delta[3 * (size_t)i + 2] = (float)d2;
+        const size_t g = a.lg[i];
+        a.delta[3 * g] = (float)d0;
+        a.delta[3 * g + 1] = (float)d1;
+        a.delta[3 * g + 2] = (float)d2;
     }
 }
 
@@ -1097,6 +1096,7 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
     tc_fill_const(c, &a.k);
     a.step = step;
     a.delta = c->delta;
+    a.lg = c->lg;
     a.flags = c->flags;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
@@ -1336,7 +1336,10 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
          * replay it exactly from the carried hsml with the plain code */
     }
 
-    if (finite && !d.ok && isfinite(d.hsml)) density_loop(da, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d);
+    if (finite && !d.ok && isfinite(d.hsml)) {
+        const float rmax = k.margin_on ? tc_margin_radius(da.hsml_in[i], pi.w, k.boxsize) : HUGE_VALF;
+        density_loop(da, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d, rmax);
+    }
     if (finite) density_store<STATS>(da, i, d);
 
     if (do_wvt) {
@@ -1373,11 +1376,11 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
 {
     tc_iter_args a;
     tc_fill_const(c, &a.d.k);
-    a.d.hsml_in = c->hsml[c->cur];
+    a.d.hsml_in = c->hsml;
     a.d.guess = c->guess;
-    a.d.hsml_out = c->hsml[c->cur];
-    a.d.rho_out = c->rho[c->cur];
-    a.d.vhf_out = c->vhf[c->cur];
+    a.d.hsml_out = c->hsml;
+    a.d.rho_out = c->rho;
+    a.d.vhf_out = c->vhf;
     a.d.bias_const = -0.0116 * pow(TC_DESNNGB * 0.01, -2.236);   /* src/sph.c:206 */
     a.d.spill = c->spill;
     a.d.flags = c->flags;
@@ -1483,15 +1486,15 @@ __global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
     work_queue(a.k, [&](int i) { curl_one(a, i, idx); });
 }
 
-int tc_launch_curl(tcgpu_ctx *c)
+int tc_launch_curl(tcgpu_ctx *c, float *l_bfld)
 {
     tc_curl_args a;
     tc_fill_const(c, &a.k);
-    a.hsml = c->hsml[c->cur];
-    a.rho = c->rho[c->cur];
-    a.vhf = c->vhf[c->cur];
-    a.apot = c->apot;
-    a.bfld = c->bfld;
+    a.hsml = c->hsml;
+    a.rho = c->rho;
+    a.vhf = c->vhf;
+    a.apot = c->l_apot;
+    a.bfld = l_bfld;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_CURL);

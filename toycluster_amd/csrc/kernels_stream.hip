@@ -16,26 +16,161 @@
 
 #define TB 256
 
-/* ------------------------------------------------------------------ K1 keys */
+/* ------------------------------------------------------------------ interest mask + local set
 
-__global__ __launch_bounds__(TB) void k_keys(const float4 *__restrict__ pos4, int n, double box,
-                                             tc_u128 *__restrict__ key, uint32_t *__restrict__ idx,
-                                             int *__restrict__ flags)
+ * Sharded contexts hold every POSITION (all-gathered after each move) but build their search structures only
+ * over the particles their own queries can reach: the own index range plus a ghost shell.  The shell comes from an
+ * "interest pyramid": one bit per octree cell of levels 1..lp_max (dense (x, y, z) layout of tc_level_offset).
+ * Every own particle marks the <= 3^3 cells its ball of radius tc_margin_radius() overlaps at the level whose
+ * cell edge is >= that radius; a particle belongs to the local set when the cell holding it is marked at any
+ * level.  Both sides pad like the cell-table query does (query_setup in kernels_ngb.hip), so every particle a
+ * permitted query can accept is in the set; queries beyond the margin radius are refused by the solver kernels
+ * and the pass is repeated (api.hip). */
+__global__ __launch_bounds__(TB) void k_mark_interest(const float4 *__restrict__ gpos4, const float *__restrict__ ghsml,
+                                                      int lo, int hi, double box, double box_mant, int box_exp,
+                                                      double level_scale, int level_shift, int lmax, int lp_max,
+                                                      uint32_t *__restrict__ imask, int *__restrict__ lvl_range)
+{
+    int g = lo + blockIdx.x * TB + threadIdx.x;
+    if (g >= hi) return;
+    const float4 p = gpos4[g];
+    const float h0 = ghsml[g];
+    const float rg = tc_margin_radius(h0, p.w, box);
+    /* table levels the own queries of this pass can ask for: from the margin radius up to the first query */
+    const int la = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, rg);
+    const int lb = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, h0);
+    atomicMin(&lvl_range[0], la);
+    atomicMax(&lvl_range[1], lb);
+    /* marking level: cell edge s >= padded radius > s/2 (clamped to the pyramid) */
+    const double rp = (double)rg * (1.0 + 1e-5) + box * 2e-6;
+    int L = 1;
+    if (rp < box) {
+        const int er = __builtin_amdgcn_frexp_exp(rp) - 1;
+        const double mr = 2 * __builtin_amdgcn_frexp_mant(rp);
+        L = box_exp - er - (box_mant < mr ? 1 : 0);              /* floor(log2(box / rp)) */
+    }
+    if (L < 1) L = 1;
+    if (L > lp_max) L = lp_max;
+    const int nL = 1 << L;
+    const double inv_s = (double)nL / box;
+    int c0[3], nc[3];
+    const float xs[3] = {p.x, p.y, p.z};
+    for (int d = 0; d < 3; d++) {
+        int a = (int)floor(((double)xs[d] - rp) * inv_s), b = (int)floor(((double)xs[d] + rp) * inv_s);
+        int n = b - a + 1;
+        if (n >= nL) { n = nL; a = 0; }
+        c0[d] = a; nc[d] = n;
+    }
+    const size_t off = tc_level_offset(L);
+    for (int ix = 0; ix < nc[0]; ix++)
+        for (int iy = 0; iy < nc[1]; iy++)
+            for (int iz = 0; iz < nc[2]; iz++) {
+                const size_t x = (size_t)((c0[0] + ix) & (nL - 1)), y = (size_t)((c0[1] + iy) & (nL - 1)),
+                             z = (size_t)((c0[2] + iz) & (nL - 1));
+                const size_t bit = off + (x * nL + y) * nL + z;
+                const uint32_t m = 1u << (bit & 31);
+                if (!(imask[bit >> 5] & m)) atomicOr(&imask[bit >> 5], m);
+            }
+}
+
+/* is particle p inside the interest mask?  (orphans -- a coordinate == boxsize, see k_cells -- always are: every
+ * query that touches the periodic boundary tests them by brute force) */
+struct tc_in_mask {
+    const float4 *gpos4;
+    const uint32_t *imask;
+    double box;
+    int lp_max;
+    __device__ bool operator()(uint32_t g) const
+    {
+        const float4 p = gpos4[g];
+        uint64_t X[3];
+        tc_scaled_coords(p.x, p.y, p.z, box, X);
+        if (((X[0] | X[1] | X[2]) >> 63) != 0) return true;
+        for (int L = 1; L <= lp_max; L++) {
+            const int sh = 63 - L;
+            const size_t nL = (size_t)1 << L;
+            const size_t bit = tc_level_offset(L) + (((size_t)(X[2] >> sh) * nL) + (size_t)(X[0] >> sh)) * nL + (size_t)(X[1] >> sh);
+            if (imask[bit >> 5] & (1u << (bit & 31))) return true;
+        }
+        return false;
+    }
+};
+
+struct tc_in_range {
+    const uint32_t *lg;
+    uint32_t lo, hi;
+    __device__ bool operator()(uint32_t i) const { const uint32_t g = lg[i]; return g >= lo && g < hi; }
+};
+
+int tc_select_temp_bytes(size_t n, size_t *bytes)
+{
+    size_t b = 0;
+    auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), tc_in_range{nullptr, 0, 0});
+    hipError_t e = rocprim::select(nullptr, b, rocprim::counting_iterator<uint32_t>(0), flags, (uint32_t *)nullptr,
+                                   (int *)nullptr, n);
+    *bytes = b;
+    return e == hipSuccess ? 0 : -1;
+}
+
+int tc_launch_mark_interest(tcgpu_ctx *c)
+{
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    const size_t nbits = tc_level_offset(c->lp_max + 1);
+    int e2 = 0;
+    const double mant = 2 * frexp(c->par.boxsize, &e2);
+    const int init[2] = {TC_MAX_LEVEL + 1, 0};
+    TC_HIP(c, hipMemsetAsync(c->imask, 0, (nbits / 32 + 1) * sizeof(uint32_t), c->stream));
+    TC_HIP(c, hipMemcpyAsync(c->lvl_range, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    if (hi > lo)
+        k_mark_interest<<<(unsigned)((hi - lo + TB - 1) / TB), TB, 0, c->stream>>>(
+            c->g_pos4[c->gcur], c->g_hsml[c->gcur], (int)lo, (int)hi, c->par.boxsize, mant, e2 - 1, c->level_scale,
+            c->level_shift, c->lmax, c->lp_max, c->imask, c->lvl_range);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+/* lsel = ascending global indices of the particles inside the mask; *nloc their number (synchronises) */
+int tc_select_local(tcgpu_ctx *c, int64_t *nloc)
+{
+    tc_in_mask pred{c->g_pos4[c->gcur], c->imask, c->par.boxsize, c->lp_max};
+    auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), pred);
+    size_t b = c->sel_tmp_bytes;
+    hipError_t e = rocprim::select(c->sel_tmp, b, rocprim::counting_iterator<uint32_t>(0), flags, c->lsel, c->d_count,
+                                   (size_t)c->n, c->stream);
+    TC_HIP(c, e);
+    int h[3] = {0, 0, 0};
+    TC_HIP(c, hipMemcpyAsync(&h[0], c->d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    TC_HIP(c, hipMemcpyAsync(&h[1], c->lvl_range, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    TC_HIP(c, hipStreamSynchronize(c->stream));
+    *nloc = h[0];
+    c->lmin_tab = h[1] < 1 ? 1 : (h[1] > c->lmax ? c->lmax : h[1]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ K1 keys (of the local set) */
+
+__global__ __launch_bounds__(TB) void k_keys_local(const float4 *__restrict__ gpos4, const uint32_t *__restrict__ lsel,
+                                                   int nloc, double box, uint32_t own_lo, uint32_t own_hi,
+                                                   tc_u128 *__restrict__ key, uint32_t *__restrict__ idx,
+                                                   tc_u128 *__restrict__ gkey, int *__restrict__ flags)
 {
     int i = blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
-    float4 p = pos4[i];
+    if (i >= nloc) return;
+    const uint32_t g = lsel ? lsel[i] : (uint32_t)i;
+    float4 p = gpos4[g];
     double x = (double)p.x / box, y = (double)p.y / box, z = (double)p.z / box;
     /* src/peano.c:130-132 Assert: coordinates must be inside [0,1] (NaN fails too) */
     if (!(x >= 0 && x <= 1 && y >= 0 && y <= 1 && z >= 0 && z <= 1)) {
         atomicOr(&flags[1], 1);
-        x = y = z = 0;
         p.x = p.y = p.z = 0;
     }
     uint64_t hi, lo;
     tc_peano_key(p.x, p.y, p.z, box, &hi, &lo);
-    key[i] = ((tc_u128)hi << 64) | lo;
+    const tc_u128 k = ((tc_u128)hi << 64) | lo;
+    key[i] = k;
     idx[i] = (uint32_t)i;
+    if (g >= own_lo && g < own_hi) gkey[g] = k;          /* P[].Key of the own range (src/peano.c:70), for the presentation */
 }
 
 __global__ __launch_bounds__(TB) void k_keys_xyz(const double *__restrict__ xyz, int64_t n,
@@ -54,11 +189,15 @@ __global__ __launch_bounds__(TB) void k_keys_xyz(const double *__restrict__ xyz,
     khi[i] = hi; klo[i] = lo;
 }
 
-int tc_launch_keys(tcgpu_ctx *c)
+int tc_launch_keys_local(tcgpu_ctx *c)
 {
-    int n = (int)c->n;
+    const int n = (int)c->nloc;
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
     tc_phase_begin(c, PH_KEYS);
-    k_keys<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->key, c->idx, c->flags);
+    k_keys_local<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->g_pos4[c->gcur], c->local_full ? nullptr : c->lsel, n,
+                                                         c->par.boxsize, (uint32_t)lo, (uint32_t)hi, c->key, c->idx,
+                                                         c->g_key, c->flags);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -71,9 +210,130 @@ int tc_launch_keys_xyz(tcgpu_ctx *c, int64_t n, const double *d_xyz, uint64_t *d
     return 0;
 }
 
-/* ------------------------------------------------------------------ K3 permutation */
+/* ------------------------------------------------------------------ K3 gather into sorted local order
+ *
+ * The reference permutes P and SphP in place every pass (src/peano.c:85-126).  Here the global arrays keep
+ * their order G between presentations; a pass gathers what its kernels read -- position, WVT hsml and the
+ * carried smoothing length -- into the Peano-sorted local arrays and remembers the way back (lg). */
+__global__ __launch_bounds__(TB) void k_gather_local(int nloc, const uint32_t *__restrict__ perm,
+                                                     const uint32_t *__restrict__ lsel,
+                                                     const float4 *__restrict__ gpos4, const float *__restrict__ ghsml,
+                                                     uint32_t *__restrict__ lg, float4 *__restrict__ pos4,
+                                                     float *__restrict__ hsml)
+{
+    int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= nloc) return;
+    const uint32_t s = perm[i];
+    const uint32_t g = lsel ? lsel[s] : s;
+    lg[i] = g;
+    pos4[i] = gpos4[g];
+    hsml[i] = ghsml[g];
+}
 
-__global__ __launch_bounds__(TB) void k_permute(int n, const uint32_t *__restrict__ perm,
+int tc_launch_gather_local(tcgpu_ctx *c)
+{
+    const int n = (int)c->nloc;
+    tc_phase_begin(c, PH_PERMUTE);
+    k_gather_local<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->idx_sorted, c->local_full ? nullptr : c->lsel,
+                                                           c->g_pos4[c->gcur], c->g_hsml[c->gcur], c->lg, c->pos4, c->hsml);
+    hipError_t e = hipSuccess;
+    if (c->nranks > 1) {              /* the own particles' slots, ascending (their number is known: the own range) */
+        int64_t lo, hi;
+        tc_own_range(c, &lo, &hi);
+        auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0),
+                                                      tc_in_range{c->lg, (uint32_t)lo, (uint32_t)hi});
+        size_t b = c->sel_tmp_bytes;
+        e = rocprim::select(c->sel_tmp, b, rocprim::counting_iterator<uint32_t>(0), flags, c->own_list, c->d_count + 1,
+                            (size_t)n, c->stream);
+        c->nown = hi - lo;
+    } else {
+        c->nown = c->nloc;
+    }
+    tc_phase_end(c);
+    TC_HIP(c, e);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+/* results of the own particles back into G order */
+__global__ __launch_bounds__(TB) void k_scatter_results(int nown, const uint32_t *__restrict__ own,
+                                                        const uint32_t *__restrict__ lg, const float *__restrict__ hsml,
+                                                        const float *__restrict__ rho, const float *__restrict__ vhf,
+                                                        float *__restrict__ ghsml, float *__restrict__ grho,
+                                                        float *__restrict__ gvhf)
+{
+    int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= nown) return;
+    const uint32_t i = own ? own[t] : (uint32_t)t;
+    const uint32_t g = lg[i];
+    ghsml[g] = hsml[i];
+    grho[g] = rho[i];
+    gvhf[g] = vhf[i];
+}
+
+int tc_launch_scatter_results(tcgpu_ctx *c)
+{
+    const int n = (int)c->nown;
+    if (n <= 0) return 0;
+    k_scatter_results<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->nranks > 1 ? c->own_list : nullptr, c->lg, c->hsml,
+                                                              c->rho, c->vhf, c->g_hsml[c->gcur], c->g_rho[c->gcur],
+                                                              c->g_vhf[c->gcur]);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(TB) void k_scatter_rho(int nown, const uint32_t *__restrict__ own, const uint32_t *__restrict__ lg,
+                                                    const float *__restrict__ rho, float *__restrict__ grho)
+{
+    int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= nown) return;
+    const uint32_t i = own ? own[t] : (uint32_t)t;
+    grho[lg[i]] = rho[i];
+}
+
+int tc_launch_scatter_rho(tcgpu_ctx *c)
+{
+    const int n = (int)c->nown;
+    if (n <= 0) return 0;
+    k_scatter_rho<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->nranks > 1 ? c->own_list : nullptr, c->lg, c->rho,
+                                                          c->g_rho[c->gcur]);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(TB) void k_refresh_w(int n, const uint32_t *__restrict__ lg, const float4 *__restrict__ gpos4,
+                                                  float4 *__restrict__ pos4)
+{
+    int i = blockIdx.x * TB + threadIdx.x;
+    if (i < n) pos4[i].w = gpos4[lg[i]].w;
+}
+
+int tc_launch_refresh_w(tcgpu_ctx *c)
+{
+    const int n = (int)c->nloc;
+    k_refresh_w<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->lg, c->g_pos4[c->gcur], c->pos4);
+    TC_HIP(c, hipGetLastError());
+    c->mirror_valid = 0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ presentation: G <- Peano order */
+
+__global__ __launch_bounds__(TB) void k_iota(uint32_t *__restrict__ dst, size_t n, uint32_t first)
+{
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) dst[i] = first + (uint32_t)i;
+}
+
+int tc_launch_iota(tcgpu_ctx *c, uint32_t *dst, size_t n, uint32_t first)
+{
+    if (n == 0) return 0;
+    k_iota<<<(unsigned)((n + TB - 1) / TB), TB, 0, c->stream>>>(dst, n, first);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(TB) void k_present(int n, const uint32_t *__restrict__ perm,
                                                 const float4 *__restrict__ p_in, float4 *__restrict__ p_out,
                                                 const int32_t *__restrict__ id_in, int32_t *__restrict__ id_out,
                                                 const float *__restrict__ h_in, float *__restrict__ h_out,
@@ -92,16 +352,32 @@ __global__ __launch_bounds__(TB) void k_permute(int n, const uint32_t *__restric
     m_out[i] = m_in[s];
 }
 
-int tc_launch_permute(tcgpu_ctx *c)
+/* side arrays without a second copy (hwvt, rhom_next: width 1; delta: width 3) go through a scratch buffer */
+__global__ __launch_bounds__(TB) void k_permute_rows(int n, int width, const uint32_t *__restrict__ perm,
+                                                     const float *__restrict__ in, float *__restrict__ out)
 {
-    int n = (int)c->n, a = c->cur, b = 1 - c->cur;
-    tc_phase_begin(c, PH_PERMUTE);
-    k_permute<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->idx_sorted, c->pos4[a], c->pos4[b], c->id[a], c->id[b],
-                                                       c->hsml[a], c->hsml[b], c->rho[a], c->rho[b],
-                                                       c->vhf[a], c->vhf[b], c->rhom[a], c->rhom[b]);
-    tc_phase_end(c);
+    int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = perm[i];
+    for (int q = 0; q < width; q++) out[(size_t)width * i + q] = in[(size_t)width * s + q];
+}
+
+int tc_launch_present_permute(tcgpu_ctx *c, const uint32_t *perm)
+{
+    const int n = (int)c->n, a = c->gcur, b = 1 - c->gcur;
+    const unsigned g = (n + TB - 1) / TB;
+    k_present<<<g, TB, 0, c->stream>>>(n, perm, c->g_pos4[a], c->g_pos4[b], c->g_id[a], c->g_id[b], c->g_hsml[a],
+                                       c->g_hsml[b], c->g_rho[a], c->g_rho[b], c->g_vhf[a], c->g_vhf[b], c->g_rhom[a],
+                                       c->g_rhom[b]);
+    float *tmp = c->guess;                                   /* 3*cap floats of scratch (see ensure_capacity) */
+    float *side[3] = {c->hwvt, c->rhom_next, c->delta};
+    const int width[3] = {1, 1, 3};
+    for (int q = 0; q < 3; q++) {
+        k_permute_rows<<<g, TB, 0, c->stream>>>(n, width[q], perm, side[q], tmp);
+        TC_HIP(c, hipMemcpyAsync(side[q], tmp, (size_t)n * width[q] * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
     TC_HIP(c, hipGetLastError());
-    c->cur = b;
+    c->gcur = b;
     return 0;
 }
 
@@ -137,7 +413,7 @@ __device__ __forceinline__ int first_diff_level(const uint32_t a[3], const uint3
     return lmax - top;                /* bit lmax-1 <-> level 1 */
 }
 
-__global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, int n, double box, int lmax,
+__global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, int n, double box, int lmax, int lmin_tab,
                                               uint2 *__restrict__ cells,
                                               uint32_t *__restrict__ orphans, int *__restrict__ norph,
                                               int *__restrict__ flags)
@@ -158,6 +434,7 @@ __global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, i
     int dprev = op ? 1 : first_diff_level(ci, cp, lmax);   /* head at every level >= dprev */
     int dnext = on ? 1 : first_diff_level(ci, cn, lmax);   /* tail at every level >= dnext */
     int dmin = dprev < dnext ? dprev : dnext;
+    if (dmin < lmin_tab) dmin = lmin_tab;                  /* levels no query of this pass can ask for are not built */
     for (int L = lmax; L >= dmin; L--) {
         int sh = lmax - L;
         size_t nL = (size_t)1 << L;
@@ -170,12 +447,12 @@ __global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, i
 
 int tc_launch_cells(tcgpu_ctx *c)
 {
-    int n = (int)c->n;
-    size_t ncell = tc_level_offset(c->lmax + 1);
+    int n = (int)c->nloc;
+    const size_t first = tc_level_offset(c->lmin_tab), ncell = tc_level_offset(c->lmax + 1) - first;
     tc_phase_begin(c, PH_CELLS);
-    TC_HIP(c, hipMemsetAsync(c->cells, 0, ncell * sizeof(uint2), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->cells + first, 0, ncell * sizeof(uint2), c->stream));
     TC_HIP(c, hipMemsetAsync(c->norph, 0, sizeof(int), c->stream));
-    k_cells<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->cells,
+    k_cells<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4, n, c->par.boxsize, c->lmax, c->lmin_tab, c->cells,
                                                      c->orphans, c->norph, c->flags);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
@@ -234,7 +511,7 @@ int tc_launch_mirror(tcgpu_ctx *c)
 {
     c->mirror_valid = 0;
     if (!c->rows || c->lmax_rm <= 0 || !c->index_valid) return 0;
-    const int n = (int)c->n;
+    const int n = (int)c->nloc;
     /* scan only the mirrored levels; `cum` is addressed with whole-table cell offsets through a pointer
      * shifted back by the offset of the first mirrored level (tc_cum_base) */
     const size_t first = tc_level_offset(c->lmin_rm);
@@ -244,7 +521,7 @@ int tc_launch_mirror(tcgpu_ctx *c)
     size_t b = c->scan_tmp_bytes;
     hipError_t e = rocprim::exclusive_scan(c->scan_tmp, b, in, c->cum, 0u, ncell, rocprim::plus<uint32_t>(), c->stream);
     if (e == hipSuccess)
-        k_mirror<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize, c->lmax, c->lmin_rm, c->lmax_rm,
+        k_mirror<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4, n, c->par.boxsize, c->lmax, c->lmin_rm, c->lmax_rm,
                                                          c->cells, tc_cum_base(c), c->mirror, c->mirror_idx);
     tc_phase_end(c);
     TC_HIP(c, e);
@@ -329,7 +606,7 @@ __global__ __launch_bounds__(TB) void k_guess(const tc_u128 *__restrict__ key, i
 
 int tc_launch_guess(tcgpu_ctx *c)
 {
-    int n = (int)c->n;
+    int n = (int)c->nloc;                        /* cold passes run on the full set: the tree the guess reads is global */
     tc_phase_begin(c, PH_GUESS);
     k_guess<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->key_sorted, n, c->par.boxsize, c->guess);
     tc_phase_end(c);
@@ -337,11 +614,22 @@ int tc_launch_guess(tcgpu_ctx *c)
     return 0;
 }
 
-/* ------------------------------------------------------------------ block reductions */
+/* ------------------------------------------------------------------ exact block reductions
+ *
+ * Sums that decide control flow (the mean density error, the normalisation of the model hsml) are accumulated
+ * as 128-bit fixed-point integers: integer addition is associative, so the result does not depend on how the
+ * particles are split over threads, blocks or GPUs.  A block leaves {sum lo, sum hi, count, max} in four 64-bit
+ * slots; k_final_exact adds the blocks and writes the total as three 40-bit limbs in doubles (exact, and still
+ * exact after an all-reduce over up to 2^13 ranks) plus count and max. */
+typedef unsigned __int128 tc_u128s;
 
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ tc_u128s wave_sum_u128(tc_u128s v)
 {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t lo = __shfl_xor((unsigned long long)(uint64_t)v, o);
+        const uint64_t hi = __shfl_xor((unsigned long long)(uint64_t)(v >> 64), o);
+        v += ((tc_u128s)hi << 64) | lo;
+    }
     return v;
 }
 __device__ __forceinline__ double wave_max(double v)
@@ -349,35 +637,59 @@ __device__ __forceinline__ double wave_max(double v)
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
-
-/* reduce up to 3 sums + 1 max per block into out[block*4 .. +3] (fixed order => deterministic) */
-__device__ __forceinline__ void block_reduce4(double s0, double s1, double s2, double mx, double *out)
+__device__ __forceinline__ double wave_sum(double v)
 {
-    __shared__ double sh[4][TB / 64];
-    int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); mx = wave_max(mx);
-    if (l == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = mx; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void block_reduce_exact(tc_u128s s, double cnt, double mx, uint64_t *out)
+{
+    __shared__ uint64_t sh[4][TB / 64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    s = wave_sum_u128(s); cnt = wave_sum(cnt); mx = wave_max(mx);          /* counts are integers: exact in f64 */
+    if (l == 0) { sh[0][w] = (uint64_t)s; sh[1][w] = (uint64_t)(s >> 64); sh[2][w] = __double_as_longlong(cnt); sh[3][w] = __double_as_longlong(mx); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = 0, b = 0, cc = 0, m = 0;
-        for (int k = 0; k < TB / 64; k++) { a += sh[0][k]; b += sh[1][k]; cc += sh[2][k]; m = fmax(m, sh[3][k]); }
-        out[0] = a; out[1] = b; out[2] = cc; out[3] = m;
+        tc_u128s a = 0;
+        double b = 0, m = 0;
+        for (int k = 0; k < TB / 64; k++) {
+            a += ((tc_u128s)sh[1][k] << 64) | sh[0][k];
+            b += __longlong_as_double(sh[2][k]);
+            m = fmax(m, __longlong_as_double(sh[3][k]));
+        }
+        out[0] = (uint64_t)a; out[1] = (uint64_t)(a >> 64); out[2] = __double_as_longlong(b); out[3] = __double_as_longlong(m);
     }
 }
 
-__global__ __launch_bounds__(TB) void k_final4(const double *__restrict__ part, int nblocks, double *__restrict__ fin)
+/* fin[0..2] = 40-bit limbs of the total, fin[3] = count, fin[4] = max */
+__global__ __launch_bounds__(TB) void k_final_exact(const uint64_t *__restrict__ part, int nblocks, double *__restrict__ fin)
 {
-    double s0 = 0, s1 = 0, s2 = 0, mx = 0;
+    tc_u128s s = 0;
+    double cnt = 0, mx = 0;
     for (int b = threadIdx.x; b < nblocks; b += TB) {
-        s0 += part[4 * b]; s1 += part[4 * b + 1]; s2 += part[4 * b + 2]; mx = fmax(mx, part[4 * b + 3]);
+        s += ((tc_u128s)part[4 * b + 1] << 64) | part[4 * b];
+        cnt += __longlong_as_double(part[4 * b + 2]);
+        mx = fmax(mx, __longlong_as_double(part[4 * b + 3]));
     }
-    block_reduce4(s0, s1, s2, mx, fin);
+    __shared__ uint64_t tot[4];
+    block_reduce_exact(s, cnt, mx, tot);
+    if (threadIdx.x == 0) {
+        const tc_u128s t = ((tc_u128s)tot[1] << 64) | tot[0];
+        const uint64_t m40 = ((uint64_t)1 << 40) - 1;
+        fin[0] = (double)((uint64_t)t & m40);
+        fin[1] = (double)((uint64_t)(t >> 40) & m40);
+        fin[2] = (double)(uint64_t)(t >> 80);
+        fin[3] = __longlong_as_double(tot[2]);
+        fin[4] = __longlong_as_double(tot[3]);
+    }
 }
 
-/* the four error flags as 0/1 doubles, so that they can ride in the pass's all-reduce (api.hip) */
+/* the error flags as 0/1 doubles, so that they can ride in the pass's all-reduce (api.hip) */
 __global__ void k_flags_to_f64(const int *__restrict__ flags, double *__restrict__ out)
 {
     if (threadIdx.x < 4) out[threadIdx.x] = flags[threadIdx.x] != 0 ? 1.0 : 0.0;
+    if (threadIdx.x == 4) out[4] = flags[5] != 0 ? 1.0 : 0.0;
 }
 
 int tc_launch_flags_to_f64(tcgpu_ctx *c, double *d_out)
@@ -402,7 +714,7 @@ __global__ __launch_bounds__(TB) void k_model(const float4 *__restrict__ pos4, i
 int tc_launch_model(tcgpu_ctx *c, float *d_out)
 {
     int n = (int)c->n;
-    k_model<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize * 0.5, c->d_halo,
+    k_model<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->g_pos4[c->gcur], n, c->par.boxsize * 0.5, c->d_halo,
                                                      c->par.nhalos, d_out);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -410,34 +722,36 @@ int tc_launch_model(tcgpu_ctx *c, float *d_out)
 
 /* ------------------------------------------------------------------ K6 error sums */
 
-/* src/wvt_relax.c:73-85 over [lo,hi) */
+/* src/wvt_relax.c:73-85 over the own range [lo,hi) of G.  err is an f32; it enters the sum as the integer
+ * trunc(err * 2^36) (exact for every err >= 2^-12, 1.5e-11 absolute below; errors above 1.3e8 saturate). */
 __global__ __launch_bounds__(TB) void k_error(const float4 *__restrict__ pos4, const float *__restrict__ rho_sph,
                                               int lo, int hi, double boxhalf,
                                               const tc_halo_dev *__restrict__ halo, int nhalos,
-                                              double *__restrict__ part)
+                                              uint64_t *__restrict__ part)
 {
-    double s = 0, cnt = 0, mx = 0;
+    tc_u128s s = 0;
+    double cnt = 0, mx = 0;
     for (int i = lo + blockIdx.x * TB + threadIdx.x; i < hi; i += gridDim.x * TB) {
         float4 p = pos4[i];
         float rho = tc_density_model(p.x, p.y, p.z, boxhalf, halo, nhalos);
         float err = (float)(fabs((double)(rho_sph[i] - rho)) / (double)rho);
         mx = fmax((double)err, mx);
-        s += (double)err;
+        const double e36 = (double)err * TC_ERR_SCALE;
+        s += (tc_u128s)(e36 < 9.0e18 ? (uint64_t)e36 : (uint64_t)9.0e18);    /* NaN -> saturated too (flags report it) */
         cnt += 1;
     }
-    block_reduce4(s, cnt, 0, mx, part + 4 * blockIdx.x);
+    block_reduce_exact(s, cnt, mx, part + 4 * blockIdx.x);
 }
 
 int tc_launch_error(tcgpu_ctx *c)
 {
-    int lo = (int)(c->rank * c->shard_len), hi = (int)((c->rank + 1) * c->shard_len);
-    if (hi > c->n) hi = (int)c->n;
-    if (lo > hi) lo = hi;
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
     int nb = TC_RED_BLOCKS;
     tc_phase_begin(c, PH_ERROR);
-    k_error<<<nb, TB, 0, c->stream>>>(c->pos4[c->cur], c->rho[c->cur], lo, hi, c->par.boxsize * 0.5, c->d_halo,
-                                      c->par.nhalos, c->red);
-    k_final4<<<1, TB, 0, c->stream>>>(c->red, nb, c->red + 4 * TC_RED_BLOCKS);
+    k_error<<<nb, TB, 0, c->stream>>>(c->g_pos4[c->gcur], c->g_rho[c->gcur], (int)lo, (int)hi, c->par.boxsize * 0.5,
+                                      c->d_halo, c->par.nhalos, (uint64_t *)c->red);
+    k_final_exact<<<1, TB, 0, c->stream>>>((const uint64_t *)c->red, nb, tc_pass_scalars(c));
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -445,48 +759,65 @@ int tc_launch_error(tcgpu_ctx *c)
 
 /* ------------------------------------------------------------------ K7/K8 model hsml */
 
-/* src/wvt_relax.c:108-118 */
-__global__ __launch_bounds__(TB) void k_model_hsml(const float4 *__restrict__ pos4, int n, double boxhalf,
-                                                   double mpart, const tc_halo_dev *__restrict__ halo, int nhalos,
+/* src/wvt_relax.c:108-118 over the own range.  h^3 (f32) enters the sum as the integer trunc(h^3 / unit), `unit` a
+ * power of two 2^30 below the smallest h^3 the model allows (tc_h3_unit): exact for density contrasts up to 2^33. */
+__global__ __launch_bounds__(TB) void k_model_hsml(const float4 *__restrict__ pos4, int lo, int hi, double boxhalf,
+                                                   double mpart, double inv_unit, const tc_halo_dev *__restrict__ halo, int nhalos,
                                                    float *__restrict__ rhom, float *__restrict__ hw,
-                                                   double *__restrict__ part)
+                                                   uint64_t *__restrict__ part)
 {
-    double s = 0;
-    for (int i = blockIdx.x * TB + threadIdx.x; i < n; i += gridDim.x * TB) {
+    tc_u128s s = 0;
+    for (int i = lo + blockIdx.x * TB + threadIdx.x; i < hi; i += gridDim.x * TB) {
         float4 p = pos4[i];
         float rho = tc_density_model(p.x, p.y, p.z, boxhalf, halo, nhalos);
         rhom[i] = rho;
         float h = (float)pow(TC_DESNNGB * mpart / (double)rho / TC_FOURPITHIRD, 1. / 3.);
         hw[i] = h;
-        s += (double)(h * h * h);
+        const double h3 = (double)(h * h * h) * inv_unit;
+        s += (tc_u128s)(h3 < 9.0e18 ? (uint64_t)h3 : (uint64_t)9.0e18);
     }
-    block_reduce4(s, 0, 0, 0, part + 4 * blockIdx.x);
+    block_reduce_exact(s, 0, 0, part + 4 * blockIdx.x);
 }
 
-/* src/wvt_relax.c:120-124; the normalised value also goes into pos4.w for the sweep's gathers */
-__global__ __launch_bounds__(TB) void k_scale_hsml(float4 *__restrict__ pos4, int n, const double *__restrict__ fin,
-                                                   float *__restrict__ hw)
+/* src/wvt_relax.c:120-124; the normalised value also goes into g_pos4.w for the sweep's gathers */
+__global__ __launch_bounds__(TB) void k_scale_hsml(float4 *__restrict__ pos4, int lo, int hi, const double *__restrict__ fin,
+                                                   double unit, float *__restrict__ hw)
 {
-    int i = blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
-    float norm = (float)pow(TC_DESNNGB / fin[0] / TC_FOURPITHIRD, 1.0 / 3.0);
+    int i = lo + blockIdx.x * TB + threadIdx.x;
+    if (i >= hi) return;
+    const double sum_h3 = tc_limbs_to_double(fin[0], fin[1], fin[2], unit);
+    float norm = (float)pow(TC_DESNNGB / sum_h3 / TC_FOURPITHIRD, 1.0 / 3.0);
     float h = hw[i] * norm;
     hw[i] = h;
     pos4[i].w = h;
 }
 
-int tc_launch_model_hsml(tcgpu_ctx *c)
+int tc_launch_model_hsml_own(tcgpu_ctx *c)
 {
-    int n = (int)c->n, nb = TC_RED_BLOCKS;
-    double *fin = c->red + 4 * TC_RED_BLOCKS + 16;        /* [0..7] error pass, [8..15] flag agreement, [16..19] here */
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    int nb = TC_RED_BLOCKS;
     tc_phase_begin(c, PH_MODEL_HSML);
     /* Rho_Model goes to a side buffer: the reference stores it when the sweep runs (wvt_relax.c:113),
      * so it is committed by tc_launch_commit_rhom(), not on iterations that stop before the sweep */
-    k_model_hsml<<<nb, TB, 0, c->stream>>>(c->pos4[c->cur], n, c->par.boxsize * 0.5, c->par.mpart_gas, c->d_halo,
-                                           c->par.nhalos, c->rhom_next, c->hwvt, c->red);
-    k_final4<<<1, TB, 0, c->stream>>>(c->red, nb, fin);
-    k_scale_hsml<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], n, fin, c->hwvt);
-    c->mirror_valid = 0;                      /* pos4.w changed */
+    k_model_hsml<<<nb, TB, 0, c->stream>>>(c->g_pos4[c->gcur], (int)lo, (int)hi, c->par.boxsize * 0.5, c->par.mpart_gas,
+                                           1.0 / c->h3_unit, c->d_halo, c->par.nhalos, c->rhom_next, c->hwvt,
+                                           (uint64_t *)c->red);
+    k_final_exact<<<1, TB, 0, c->stream>>>((const uint64_t *)c->red, nb, tc_pass_scalars(c) + TC_PS_H3);
+    tc_phase_end(c);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int tc_launch_scale_hsml_own(tcgpu_ctx *c)
+{
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    tc_phase_begin(c, PH_MODEL_HSML);
+    if (hi > lo)
+        k_scale_hsml<<<(unsigned)((hi - lo + TB - 1) / TB), TB, 0, c->stream>>>(c->g_pos4[c->gcur], (int)lo, (int)hi,
+                                                                                tc_pass_scalars(c) + TC_PS_H3, c->h3_unit,
+                                                                                c->hwvt);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -494,29 +825,33 @@ int tc_launch_model_hsml(tcgpu_ctx *c)
 
 int tc_launch_commit_rhom(tcgpu_ctx *c)
 {
-    TC_HIP(c, hipMemcpyAsync(c->rhom[c->cur], c->rhom_next, (size_t)c->n * sizeof(float), hipMemcpyDeviceToDevice,
-                             c->stream));
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    if (hi > lo)
+        TC_HIP(c, hipMemcpyAsync(c->g_rhom[c->gcur] + lo, c->rhom_next + lo, (size_t)(hi - lo) * sizeof(float),
+                                 hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
-/* delta = step * U for the fused kernel's unit-step sums (src/wvt_relax.c:167-169 with the scalar
- * step factored out of the neighbour sum) */
-__global__ __launch_bounds__(TB) void k_apply_step(const double *__restrict__ ustep, float *__restrict__ delta,
-                                                   int lo, int hi, double step)
+/* delta (G order) = step * U for the fused kernel's unit-step sums in local order (src/wvt_relax.c:167-169 with
+ * the scalar step factored out of the neighbour sum) */
+__global__ __launch_bounds__(TB) void k_apply_step(int nown, const uint32_t *__restrict__ own, const uint32_t *__restrict__ lg,
+                                                   const double *__restrict__ ustep, float *__restrict__ delta, double step)
 {
-    int i = lo + blockIdx.x * TB + threadIdx.x;
-    if (i >= hi) return;
-    for (int c = 0; c < 3; c++) delta[3 * (size_t)i + c] = (float)(step * ustep[3 * (size_t)i + c]);
+    int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= nown) return;
+    const uint32_t i = own ? own[t] : (uint32_t)t;
+    const uint32_t g = lg[i];
+    for (int q = 0; q < 3; q++) delta[3 * (size_t)g + q] = (float)(step * ustep[3 * (size_t)i + q]);
 }
 
 int tc_launch_apply_step(tcgpu_ctx *c, double step)
 {
-    int lo = (int)(c->rank * c->shard_len), hi = (int)((c->rank + 1) * c->shard_len);
-    if (hi > c->n) hi = (int)c->n;
-    if (lo > hi) lo = hi;
+    const int n = (int)c->nown;
     tc_phase_begin(c, PH_WVT);
-    if (hi > lo)
-        k_apply_step<<<(hi - lo + TB - 1) / TB, TB, 0, c->stream>>>(c->ustep, c->delta, lo, hi, step);
+    if (n > 0)
+        k_apply_step<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->nranks > 1 ? c->own_list : nullptr, c->lg, c->ustep,
+                                                             c->delta, step);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -548,16 +883,75 @@ __global__ __launch_bounds__(TB) void k_move(float4 *__restrict__ pos4, const fl
 
 int tc_launch_move(tcgpu_ctx *c)
 {
-    int lo = (int)(c->rank * c->shard_len), hi = (int)((c->rank + 1) * c->shard_len);
-    if (hi > c->n) hi = (int)c->n;
-    if (lo > hi) lo = hi;
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
     tc_phase_begin(c, PH_MOVE);
     if (hi > lo)
-        k_move<<<(hi - lo + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4[c->cur], c->delta, lo, hi, c->par.boxsize);
+        k_move<<<(unsigned)((hi - lo + TB - 1) / TB), TB, 0, c->stream>>>(c->g_pos4[c->gcur], c->delta, (int)lo, (int)hi,
+                                                                          c->par.boxsize);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
-    c->keys_valid = 0;
     c->index_valid = 0; c->mirror_valid = 0;
     c->ustep_valid = 0;
+    c->w_valid = 0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ curl: A into local order, B back */
+
+__global__ __launch_bounds__(TB) void k_gather_rows3(int n, const uint32_t *__restrict__ lg, const float *__restrict__ in,
+                                                     float *__restrict__ out)
+{
+    int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const size_t g = lg[i];
+    for (int q = 0; q < 3; q++) out[3 * (size_t)i + q] = in[3 * g + q];
+}
+
+__global__ __launch_bounds__(TB) void k_scatter_rows3(int nown, const uint32_t *__restrict__ own, const uint32_t *__restrict__ lg,
+                                                      const float *__restrict__ in, float *__restrict__ out)
+{
+    int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= nown) return;
+    const uint32_t i = own ? own[t] : (uint32_t)t;
+    const size_t g = lg[i];
+    for (int q = 0; q < 3; q++) out[3 * g + q] = in[3 * (size_t)i + q];
+}
+
+__global__ __launch_bounds__(TB) void k_gather_rho_vhf(int n, const uint32_t *__restrict__ lg, const float *__restrict__ grho,
+                                                       const float *__restrict__ gvhf, float *__restrict__ rho,
+                                                       float *__restrict__ vhf)
+{
+    int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = lg[i];
+    rho[i] = grho[g];
+    vhf[i] = gvhf[g];
+}
+
+/* rho and varHsmlFac of the local particles (the curl reads those of the particle it solves) */
+int tc_launch_gather_rho_vhf(tcgpu_ctx *c)
+{
+    const int n = (int)c->nloc;
+    k_gather_rho_vhf<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->lg, c->g_rho[c->gcur], c->g_vhf[c->gcur], c->rho, c->vhf);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int tc_launch_gather_apot(tcgpu_ctx *c)
+{
+    const int n = (int)c->nloc;
+    k_gather_rows3<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->lg, c->apot, c->l_apot);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int tc_launch_scatter_bfld(tcgpu_ctx *c, const float *l_bfld)
+{
+    const int n = (int)c->nown;
+    if (n > 0)
+        k_scatter_rows3<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->nranks > 1 ? c->own_list : nullptr, c->lg, l_bfld,
+                                                                c->bfld);
+    TC_HIP(c, hipGetLastError());
     return 0;
 }

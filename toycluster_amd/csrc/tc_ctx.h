@@ -22,7 +22,7 @@
 
 enum tc_phase {
     PH_KEYS = 0, PH_SORT, PH_PERMUTE, PH_CELLS, PH_GUESS, PH_DENSITY, PH_ERROR, PH_MODEL_HSML,
-    PH_WVT, PH_MOVE, PH_CURL, PH_COMM, PH_MIRROR, PH_COUNT
+    PH_WVT, PH_MOVE, PH_CURL, PH_COMM, PH_MIRROR, PH_LOCAL, PH_PRESENT, PH_COUNT
 };
 
 /* Constants every neighbour kernel needs; passed by value. */
@@ -47,8 +47,11 @@ struct tc_dev_const {
     const uint32_t *mirror_idx;   /* slot -> Peano index */
     int lmax_rm, lmin_rm;         /* mirrored levels: lmin_rm..lmax_rm */
     uint32_t mirror_pad;          /* slot holding a position at infinity (padding lanes load it) */
-    int n;                        /* all particles (neighbour candidates) */
-    int lo, hi;                   /* [lo,hi): the particles this GPU solves for */
+    int n;                        /* particles of the local set (neighbour candidates) */
+    int lo, hi;                   /* work items [lo,hi): particle own[t] (own != NULL) or t itself */
+    const uint32_t *own;          /* sharded contexts: local indices of the particles this GPU solves, ascending */
+    int lmin_tab;                 /* coarsest level the cell table holds (queries are clamped to [lmin_tab, lmax]) */
+    int margin_on;                /* sharded contexts: a query beyond tc_margin_radius() must not run (ghosts end there) */
     int *work_ctr;                /* dynamic work queue: per XCD group (stride 16 ints) the next unassigned particle */
     int ablate;                   /* profiling only: 1 producer only, 2 +predicate, 3 no solver (results invalid) */
 };
@@ -59,6 +62,28 @@ TC_HD size_t tc_level_offset(int L) /* cells of levels 1..L-1 */
     for (int l = 1; l < L; l++) { o += c; c *= 8; }
     return o;
 }
+
+#if defined(__HIPCC__)
+/* table level of a query of radius h: floor(log2(box/(h*level_scale))) + 1 + level_shift, clamped to
+ * [lmin, lmax]; floor(log2) from the exponents and mantissas of the two numbers (no division).  Any level is
+ * CORRECT for any query (the cell enumeration adapts); the choice only decides how many cells and candidates a
+ * query touches. */
+__device__ __forceinline__ int tc_query_level(double boxsize, double box_mant, int box_exp, double level_scale,
+                                              int level_shift, int lmin, int lmax, float h)
+{
+    const double hd = (double)h * level_scale;
+    int L = 1;
+    if (hd <= boxsize) {
+        const int eh = __builtin_amdgcn_frexp_exp(hd) - 1;                 /* hd = mh * 2^eh, mh in [1, 2) */
+        const double mh = 2 * __builtin_amdgcn_frexp_mant(hd);
+        L = box_exp - eh - (box_mant < mh ? 1 : 0) + 1;
+    }
+    L += level_shift;
+    if (L < lmin) L = lmin;
+    if (L > lmax) L = lmax;
+    return L;
+}
+#endif
 
 struct tc_event_rec { int phase; hipEvent_t a, b; };
 
@@ -72,29 +97,61 @@ struct tcgpu_ctx {
     int have_model;
     tc_halo_dev *d_halo;
 
-    /* particles: two copies for the out-of-place permutation, `cur` is live */
+    /* GLOBAL arrays, all n particles in the order G (upload order, then the Peano order of the last
+     * "presentation", tc present() in api.hip).  Positions are complete on every rank; the per-particle state
+     * (hsml, rho, ...) is valid for the rank's own index range between presentations.  Two copies for the
+     * out-of-place permutation of a presentation, `gcur` is live. */
     int64_t n, cap;
-    int cur;
-    float4 *pos4[2];
-    int32_t *id[2];
-    float *hsml[2], *rho[2], *vhf[2], *rhom[2];
-    float *apot, *bfld;           /* 3*cap each, allocated on demand */
+    int gcur;
+    float4 *g_pos4[2];            /* x, y, z, w = WVT hsml (box units) */
+    int32_t *g_id[2];
+    float *g_hsml[2], *g_rho[2], *g_vhf[2], *g_rhom[2];
+    tc_u128 *g_key;               /* key of every particle at the last density pass (own range written per pass) */
+    tc_u128 *g_key_sorted;        /* ... in presented order (tcgpu_download_keys) */
+    int order_dirty;              /* a density pass has run since the last presentation */
+    int g_compact;                /* G is a Peano order: index ranges are spatially compact shards */
+    int w_valid;                  /* g_pos4.w / rhom_next / hwvt hold the model hsml of the current positions */
+    float *apot, *bfld;           /* 3*cap each, allocated on demand (G order) */
+    float *l_apot;                /* 3*cap, local order */
 
-    /* sort */
+    /* LOCAL set: the particles this rank's queries can reach (own range + ghosts; everything on a single rank
+     * and on cold passes), Peano-sorted every density pass */
+    int64_t nloc;
+    int local_full;               /* the local set is all n particles (then local order == presented order) */
+    uint32_t *lsel;               /* unsorted local set: global indices (ascending) */
+    uint32_t *lg;                 /* local sorted slot -> global index */
+    uint32_t *own_list;           /* local sorted slots of the own range, ascending (sharded, !local_full) */
+    int64_t nown;
+    float4 *pos4;                 /* local sorted positions (w = WVT hsml) */
+    float *hsml, *rho, *vhf;      /* local sorted: carried hsml in, results out */
+    uint32_t *imask;              /* interest pyramid: one bit per cell of levels 1..lp_max (tc_level_offset layout) */
+    int lp_max;
+    int *lvl_range;               /* device: [0] = min, [1] = max table level the own queries of this pass can use */
+    int lmin_tab;                 /* coarsest level built this pass */
+    void *sel_tmp;
+    size_t sel_tmp_bytes;
+    int *d_count;                 /* device: selected count */
+    int margin_retry;             /* passes repeated because a query left the ghost margin (diagnostic) */
+    int local_w_valid;            /* the w lane of the local positions is the current model hsml */
+    int lmax_rm0, lmin_rm0;       /* mirrored level range of a full local set (per pass: clipped to lmin_tab) */
+    double comm_bytes;            /* bytes received in collectives since the last reset */
+    double h3_unit;               /* fixed-point unit (a power of two) of the exact sum of h^3, from the model (set_model) */
+
+    /* sort (local set; also the scratch of a presentation) */
     tc_u128 *key, *key_sorted;
     uint32_t *idx, *idx_sorted;
     void *sort_tmp;
     size_t sort_tmp_bytes;
-    int keys_valid;               /* key_sorted matches the current order */
+    int keys_valid;               /* g_key_sorted matches the presented order */
 
     /* neighbour index */
     int lmax, lmax_alloc;
     uint2 *cells;
     size_t ncells_alloc;
     double *spill;                /* TC_MAX_PERSISTENT_BLOCKS*WPB x 2*NGBMAX */
-    double *ustep;                /* 3*cap: unit-step WVT displacement sums of the fused kernel */
-    float *rhom_next;             /* cap: model density at the current positions, committed by the sweep */
-    int ustep_valid;              /* ustep/rhom_next/hwvt belong to the current order and positions */
+    double *ustep;                /* 3*cap: unit-step WVT displacement sums of the fused kernel (local order) */
+    float *rhom_next;             /* cap: model density at the current positions, committed by the sweep (G order) */
+    int ustep_valid;              /* ustep belongs to the current local order and positions */
     int fuse;                     /* option: use the fused kernel (default 1) */
     int num_cu;
     uint32_t *orphans;
@@ -117,10 +174,11 @@ struct tcgpu_ctx {
 
     /* scratch */
     float *guess;
-    float *hwvt, *delta;          /* cap, 3*cap */
+    float *hwvt, *delta;          /* cap, 3*cap (G order; own range) */
     double *red;                  /* TC_RED_BLOCKS*4 partials + 32 finals */
     double *h_red;                /* pinned, 32 doubles */
-    int *flags;                   /* device: [0]=nonfinite [1]=coord range [2]=no convergence [3]=overflow [4]=wvt ngbmax hits */
+    int *flags;                   /* device: [0]=nonfinite [1]=coord range [2]=no convergence [3]=overflow [4]=wvt ngbmax hits
+                                   * [5]=a query left the ghost margin (sharded contexts: the pass is repeated) */
     int *h_flags;                 /* pinned */
     uint32_t *stats;              /* 4 x cap, optional */
     int want_stats;
@@ -163,31 +221,96 @@ struct tcgpu_ctx {
 /* `cum` holds the prefix sum of the mirrored levels only; kernels index it with whole-table cell offsets */
 static inline const uint32_t *tc_cum_base(const tcgpu_ctx *c) { return c->cum - tc_level_offset(c->lmin_rm); }
 
+/* Scalars of one pass: device doubles at tc_pass_scalars(c); api.hip all-reduces them over the ranks.
+ *   [0..2]  sum of the density errors as three 40-bit limbs of an exact fixed-point sum (2^-40 units)
+ *   [3]     particles counted                                                   -> [0..3] are SUMMED
+ *   [4]     largest density error
+ *   [5..9]  error flags as 0/1: nonfinite, coordinate range, no convergence, overflow, ghost margin
+ *                                                                               -> [4..9] are MAXIMISED
+ * and at +16: [0..2] limbs of the exact sum of h^3 of the model hsml pass (2^-20 units)  -> SUMMED
+ * Exact integer sums make every all-reduced value independent of how the particles are split over ranks,
+ * blocks and threads: a sharded run takes bit for bit the decisions of the single-GPU run. */
+#define TC_PS_NSUM 4
+#define TC_PS_NMAX 6
+#define TC_PS_FLAGS 5
+#define TC_PS_H3 16
+static inline double *tc_pass_scalars(const tcgpu_ctx *c) { return c->red + 4 * TC_RED_BLOCKS; }
+
+/* total of three (all-reduced) 40-bit limbs -> f64; exact integer recombination, one rounding */
+TC_HD double tc_limbs_to_double(double l0, double l1, double l2, double unit)
+{
+    unsigned __int128 t = ((unsigned __int128)(uint64_t)l2 << 80) + ((unsigned __int128)(uint64_t)l1 << 40)
+                          + (unsigned __int128)(uint64_t)l0;
+    return ((double)(uint64_t)(t >> 64) * 18446744073709551616.0 + (double)(uint64_t)t) * unit;
+}
+
+#define TC_ERR_SCALE 68719476736.0        /* 2^36: fixed-point unit of the exact density-error sum */
+
+/* deepest level of the interest pyramid (8^8 cells = 2 MB of bits) */
+#define TC_LP_MAX 8
+
+/* Largest radius the kernels may query for a particle with carried smoothing length h0 and WVT hsml w (box
+ * units) before a sharded pass must be repeated with more ghosts: the reference's first query (h0), its retry at
+ * 1.23 h0 (src/sph.c:49-54), one more retry, and the sweep's ball w*box (src/wvt_relax.c:135).  The marking
+ * kernel and the solver kernels evaluate this very function, so the ghost set provably covers every query that
+ * is allowed to run. */
+TC_HD float tc_margin_radius(float h0, float w, double boxsize)
+{
+    const float hb = (float)((double)h0 * 1.23);
+    const float h3 = (float)((double)hb * 1.23);
+    const float hw = (float)((double)w * boxsize);
+    const float r = h3 > hw ? h3 : hw;
+    return r * 1.000001f;
+}
+
 /* ---- launchers implemented in the kernel translation units ---- */
 int tc_sort_temp_bytes(size_t n, size_t *bytes);
 int tc_sort_pairs_u128(void *tmp, size_t tmp_bytes, const tc_u128 *kin, tc_u128 *kout,
                        const uint32_t *vin, uint32_t *vout, size_t n, int sort_bits, hipStream_t s);
 
-int tc_launch_keys(tcgpu_ctx *c);
 int tc_launch_keys_xyz(tcgpu_ctx *c, int64_t n, const double *d_xyz, uint64_t *d_hi, uint64_t *d_lo);
-int tc_launch_permute(tcgpu_ctx *c);
+/* local set */
+int tc_select_temp_bytes(size_t n, size_t *bytes);
+int tc_launch_mark_interest(tcgpu_ctx *c);      /* imask, lvl_range from the own range (g_hsml, g_pos4.w) */
+int tc_select_local(tcgpu_ctx *c, int64_t *nloc);  /* lsel = particles inside the interest mask; synchronises */
+int tc_launch_keys_local(tcgpu_ctx *c);         /* key, idx of the local set; g_key of the own range */
+int tc_launch_gather_local(tcgpu_ctx *c);       /* lg, pos4, hsml in sorted local order; own_list */
 int tc_launch_cells(tcgpu_ctx *c);
 int tc_scan_temp_bytes(size_t ncell, size_t *bytes);
-int tc_launch_mirror(tcgpu_ctx *c);             /* cum, mirror, mirror_idx from cells + pos4 (after pos4.w is final) */
+int tc_launch_mirror(tcgpu_ctx *c);             /* cum, mirror, mirror_idx from cells + pos4 */
 int tc_launch_guess(tcgpu_ctx *c);
+int tc_launch_scatter_results(tcgpu_ctx *c);    /* hsml, rho, vhf of the own particles -> G order */
+/* global arrays */
+int tc_launch_iota(tcgpu_ctx *c, uint32_t *dst, size_t n, uint32_t first);   /* dst[i] = first + i */
+int tc_launch_scatter_rho(tcgpu_ctx *c);        /* rho of the own particles -> G order (the error sums read it) */
+int tc_launch_refresh_w(tcgpu_ctx *c);          /* local pos4.w <- g_pos4.w */
+int tc_launch_present_permute(tcgpu_ctx *c, const uint32_t *perm);   /* G <- G[perm]; flips gcur */
 int tc_launch_model(tcgpu_ctx *c, float *d_out);
-int tc_launch_error(tcgpu_ctx *c);              /* -> red[0..2] = sum err, count, max err (over the shard) */
-int tc_launch_model_hsml(tcgpu_ctx *c);         /* rhom, hwvt (normalised, also into pos4.w) */
+int tc_launch_error(tcgpu_ctx *c);              /* pass scalars [0..4] over the own range */
+int tc_launch_model_hsml_own(tcgpu_ctx *c);     /* rhom_next, hwvt (not yet normalised), pass scalars +16 */
+int tc_launch_scale_hsml_own(tcgpu_ctx *c);     /* normalise with the (all-reduced) sum: hwvt, g_pos4.w */
 int tc_launch_move(tcgpu_ctx *c);
-int tc_launch_flags_to_f64(tcgpu_ctx *c, double *d_out);   /* flags[0..3] != 0 as doubles */
+int tc_launch_flags_to_f64(tcgpu_ctx *c, double *d_out);   /* flags[0..3], flags[5] != 0 as five doubles */
 int tc_launch_commit_rhom(tcgpu_ctx *c);
+int tc_launch_gather_rho_vhf(tcgpu_ctx *c);     /* rho, vhf (local) = G values */
+int tc_launch_gather_apot(tcgpu_ctx *c);        /* l_apot[i] = apot[lg[i]] */
+int tc_launch_scatter_bfld(tcgpu_ctx *c, const float *l_bfld);
+/* neighbour kernels */
 int tc_launch_density(tcgpu_ctx *c);
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt);   /* fused density (+ unit-step WVT sums) */
-int tc_launch_apply_step(tcgpu_ctx *c, double step);  /* delta = step * ustep, rhom <- rhom_next */
+int tc_launch_apply_step(tcgpu_ctx *c, double step);  /* delta (G order) = step * ustep (local order) */
 int tc_launch_wvt(tcgpu_ctx *c, double step);
-int tc_launch_curl(tcgpu_ctx *c);
+int tc_launch_curl(tcgpu_ctx *c, float *l_bfld);
 int tc_launch_find_ngb(tcgpu_ctx *c, int ipart, float hsml);
 void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k);
+/* the rank's own index range of G */
+static inline void tc_own_range(const tcgpu_ctx *c, int64_t *lo, int64_t *hi)
+{
+    int64_t a = c->rank * c->shard_len, b = (c->rank + 1) * c->shard_len;
+    if (b > c->n) b = c->n;
+    if (a > b) a = b;
+    *lo = a; *hi = b;
+}
 
 void tc_phase_begin(tcgpu_ctx *c, int phase);
 void tc_phase_end(tcgpu_ctx *c);
