@@ -41,11 +41,22 @@ static rccl_api g_rccl;
  * single-GPU box.  Never used by the product path (tcgpu_comm_init installs RCCL). */
 struct tc_loop_comm {
     int nranks;
+    int exclusive;             /* profiling: one rank computes at a time (token below), so that per-rank HIP-event
+                                * times on the one shared GPU are those of a rank alone on its own GPU */
+    pthread_mutex_t token;
     pthread_barrier_t bar;
     void *bufs[16];
     double red[16][16];
 };
 
+
+/* exclusive loopback (profiling): a rank holds the token whenever it is not waiting in a collective */
+struct tc_loop_guard {
+    tcgpu_ctx *c;
+    explicit tc_loop_guard(tcgpu_ctx *ctx);
+    ~tc_loop_guard();
+};
+static void loop_wait(tcgpu_ctx *c);
 
 /* ------------------------------------------------------------------ phase timing */
 
@@ -114,9 +125,10 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipMalloc(&c->norph, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->work_ctr, 8 * 16 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->ngb_cnt, sizeof(int)) == hipSuccess;
-    ok = ok && hipMalloc(&c->lvl_range, 2 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->lvl_range, 8 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->d_count, 4 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->imask, (tc_level_offset(TC_LP_MAX + 1) / 32 + 1) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&c->isum, ((size_t)1 << (3 * TC_LS)) / 8) == hipSuccess;
     ok = ok && hipMalloc(&c->spill, sizeof(double) * (size_t)TC_MAX_PERSISTENT_BLOCKS * TC_WAVES_PER_BLOCK
                                         * (2 * TC_NGBMAX)) == hipSuccess;
     c->fuse = 1;
@@ -160,7 +172,7 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     free_particles(c);
     hipFree(c->d_halo); hipFree(c->red); hipHostFree(c->h_red); hipFree(c->flags); hipHostFree(c->h_flags);
     hipFree(c->orphans); hipFree(c->norph); hipFree(c->work_ctr); hipFree(c->ngb_cnt); hipFree(c->spill);
-    hipFree(c->lvl_range); hipFree(c->d_count); hipFree(c->imask);
+    hipFree(c->lvl_range); hipFree(c->d_count); hipFree(c->imask); hipFree(c->isum);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);
@@ -332,6 +344,7 @@ static void set_shard(tcgpu_ctx *c)
 
 extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos, const int32_t *id, const float *hsml)
 {
+    tc_loop_guard guard_(c);
     if (!c || !pos || n <= 0) return TCGPU_ERR_ARG;
     if (n >= (1LL << 31) - 64) TC_FAIL(c, TCGPU_ERR_ARG, "n=%lld exceeds the 32-bit index range of the path", (long long)n);
     TC_HIP(c, hipSetDevice(c->device));
@@ -466,6 +479,15 @@ extern "C" int tcgpu_comm_init(tcgpu_ctx *c, int rank, int nranks, const uint8_t
 }
 
 /* In-place all-gather of one shard-partitioned array of G (elements of `esize` bytes). */
+/* loopback barrier; in exclusive mode the token is handed on while waiting */
+static void loop_wait(tcgpu_ctx *c)
+{
+    tc_loop_comm *L = c->loop;
+    if (L->exclusive) pthread_mutex_unlock(&L->token);
+    pthread_barrier_wait(&L->bar);
+    if (L->exclusive) pthread_mutex_lock(&L->token);
+}
+
 static int allgather_inplace(tcgpu_ctx *c, void *base, size_t esize)
 {
     size_t bytes = (size_t)c->shard_len * esize;
@@ -474,14 +496,14 @@ static int allgather_inplace(tcgpu_ctx *c, void *base, size_t esize)
         tc_loop_comm *L = c->loop;
         TC_HIP(c, hipStreamSynchronize(c->stream));
         L->bufs[c->rank] = base;
-        pthread_barrier_wait(&L->bar);
+        loop_wait(c);
         for (int p = 0; p < L->nranks; p++)
             if (p != c->rank)
                 TC_HIP(c, hipMemcpyAsync((char *)L->bufs[p] + (size_t)c->rank * bytes,
                                          (const char *)base + (size_t)c->rank * bytes, bytes,
                                          hipMemcpyDeviceToDevice, c->stream));
         TC_HIP(c, hipStreamSynchronize(c->stream));
-        pthread_barrier_wait(&L->bar);
+        loop_wait(c);
         return 0;
     }
     ncclResult_t r = g_rccl.AllGather((const char *)base + (size_t)c->rank * bytes, base, bytes, ncclInt8,
@@ -501,13 +523,13 @@ static int allreduce_scalars(tcgpu_ctx *c, double *buf, int nsum, int nmax)
         TC_HIP(c, hipMemcpyAsync(h, buf, nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         TC_HIP(c, hipStreamSynchronize(c->stream));
         memcpy(L->red[c->rank], h, nt * sizeof(double));
-        pthread_barrier_wait(&L->bar);
+        loop_wait(c);
         double o[16] = {0};
         for (int p = 0; p < L->nranks; p++) {
             for (int q = 0; q < nsum; q++) o[q] += L->red[p][q];
             for (int q = nsum; q < nt; q++) o[q] = fmax(o[q], L->red[p][q]);
         }
-        pthread_barrier_wait(&L->bar);
+        loop_wait(c);
         TC_HIP(c, hipMemcpyAsync(buf, o, nt * sizeof(double), hipMemcpyHostToDevice, c->stream));
         TC_HIP(c, hipStreamSynchronize(c->stream));
         return 0;
@@ -522,6 +544,18 @@ static int allreduce_scalars(tcgpu_ctx *c, double *buf, int nsum, int nmax)
 }
 
 static inline bool multi(const tcgpu_ctx *c) { return c->comm || c->loop; }
+
+tc_loop_guard::tc_loop_guard(tcgpu_ctx *ctx) : c(ctx)
+{
+    if (c && c->loop && c->loop->exclusive) pthread_mutex_lock(&c->loop->token);
+}
+tc_loop_guard::~tc_loop_guard()
+{
+    if (c && c->loop && c->loop->exclusive) {
+        hipStreamSynchronize(c->stream);
+        pthread_mutex_unlock(&c->loop->token);
+    }
+}
 
 /* multi-rank contexts: agree on the error flags (maximum over the ranks), then check them; every rank
  * returns the same status.  Single rank: the plain check. */
@@ -547,6 +581,8 @@ extern "C" int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks)
     tc_loop_comm *L = (tc_loop_comm *)calloc(1, sizeof(*L));
     if (!L) return TCGPU_ERR_NOMEM;
     L->nranks = nranks;
+    L->exclusive = getenv("TCGPU_LOOPBACK_EXCLUSIVE") != nullptr;
+    pthread_mutex_init(&L->token, nullptr);
     pthread_barrier_init(&L->bar, nullptr, (unsigned)nranks);
     for (int r = 0; r < nranks; r++) {
         if (!ctxs[r] || ctxs[r]->n > 0) { free(L); return TCGPU_ERR_ARG; }
@@ -652,12 +688,11 @@ static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
         c->nloc = c->n;
         c->lmin_tab = 1;
     } else {
+        int64_t nloc = 0;
         tc_phase_begin(c, PH_LOCAL);
         rc = tc_launch_mark_interest(c);
-        tc_phase_end(c);
+        if (!rc) rc = tc_select_local(c, &nloc);                      /* synchronises: the launch sizes below need nloc */
         if (rc) return rc;
-        int64_t nloc = 0;
-        if ((rc = tc_select_local(c, &nloc))) return rc;              /* synchronises: the launch sizes below need nloc */
         c->local_full = 0;
         c->nloc = nloc;
     }
@@ -683,6 +718,7 @@ static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
 
 extern "C" int tcgpu_sort_particles_by_peano_key(tcgpu_ctx *c)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc;
@@ -695,6 +731,7 @@ extern "C" int tcgpu_sort_particles_by_peano_key(tcgpu_ctx *c)
 extern "C" int tcgpu_download_particles(tcgpu_ctx *c, float *pos, int32_t *id, float *hsml, float *rho, float *vhf,
                                         float *rhom)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc = present(c);
@@ -722,6 +759,7 @@ extern "C" int tcgpu_download_particles(tcgpu_ctx *c, float *pos, int32_t *id, f
 
 extern "C" int tcgpu_download_keys(tcgpu_ctx *c, uint64_t *hi, uint64_t *lo)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc = present(c);
@@ -774,6 +812,7 @@ static int full_index(tcgpu_ctx *c)
 
 extern "C" int tcgpu_build_neighbour_index(tcgpu_ctx *c)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc = full_index(c);
@@ -830,15 +869,21 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
 
 extern "C" int tcgpu_find_sph_quantities(tcgpu_ctx *c)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc, full = 0;
+    c->margin_widen = 0;
     for (;;) {
         if ((rc = density_pass_launch(c, c->need_guess, 0, full))) return rc;
         rc = check_flags_collective(c);
         if (rc != TC_RETRY_FULL) break;
-        full = 1; c->margin_retry++;              /* a query left the ghost margin: the same pass on the full set */
+        /* a query left the ghost margin: the same pass again with a wider shell, at last on the full set */
+        c->margin_retry++;
+        c->margin_widen += 2;
+        if (c->margin_widen > 4) full = 1;
     }
+    c->margin_widen = 0;
     if (rc) return rc;
     if ((rc = tc_launch_scatter_results(c))) return rc;
     c->need_guess = 0;                            /* every hsml is > 0 after a successful pass */
@@ -855,6 +900,7 @@ extern "C" int tcgpu_last_density_stats(tcgpu_ctx *c, tcgpu_density_stats *out)
 
 extern "C" int tcgpu_global_density_model(tcgpu_ctx *c, float *out)
 {
+    tc_loop_guard guard_(c);
     if (!c || !out || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc = present(c);
@@ -868,6 +914,7 @@ extern "C" int tcgpu_global_density_model(tcgpu_ctx *c, float *out)
 
 extern "C" int tcgpu_guess_hsml(tcgpu_ctx *c, float *out)
 {
+    tc_loop_guard guard_(c);
     if (!c || !out || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc;
@@ -883,6 +930,7 @@ extern "C" int tcgpu_guess_hsml(tcgpu_ctx *c, float *out)
 
 extern "C" int tcgpu_find_ngb(tcgpu_ctx *c, int64_t ipart, float hsml, int32_t *list, int32_t *count)
 {
+    tc_loop_guard guard_(c);
     if (!c || !list || !count || ipart < 0 || ipart >= c->n) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc = present(c);
@@ -938,6 +986,7 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
 
 extern "C" int tcgpu_wvt_step(tcgpu_ctx *c, double step, float *hsml_wvt, float *delta, int move)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     if (c->need_guess) TC_FAIL(c, TCGPU_ERR_ARG, "no density pass yet (call tcgpu_find_sph_quantities first)");
     if (multi(c) && (hsml_wvt || delta))
@@ -967,6 +1016,7 @@ static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, do
 {
     int rc, full = 0;
     double *ps = tc_pass_scalars(c);
+    c->margin_widen = 0;
     for (;;) {
         if ((rc = density_pass_launch(c, need_guess, 1, full))) return rc;
         /* the error sums need this pass's densities in G order; the carried hsml is written back only once the
@@ -985,8 +1035,11 @@ static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, do
         TC_HIP(c, hipMemcpyAsync(c->h_red, ps, (TC_PS_NSUM + TC_PS_NMAX) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         rc = check_flags(c, multi(c) ? c->h_red + TC_PS_NSUM + 1 : nullptr);      /* synchronises the stream */
         if (rc != TC_RETRY_FULL) break;
-        full = 1; c->margin_retry++;
+        c->margin_retry++;                        /* repeat with a wider ghost shell, at last on the full set */
+        c->margin_widen += 2;
+        if (c->margin_widen > 4) full = 1;
     }
+    c->margin_widen = 0;
     if (rc) return rc;
     if ((rc = tc_launch_scatter_results(c))) return rc;
     /* exact sum -> f64 once, the same on every rank and for every split of the particles (wvt_relax.c:87) */
@@ -998,6 +1051,7 @@ static int density_error_sync(tcgpu_ctx *c, int need_guess, double *err_mean, do
 
 extern "C" int tcgpu_density_error(tcgpu_ctx *c, double *err_mean, double *err_max)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0 || !c->have_model || !err_mean || !err_max) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc = density_error_sync(c, c->need_guess, err_mean, err_max);
@@ -1010,6 +1064,7 @@ extern "C" int tcgpu_density_error(tcgpu_ctx *c, double *err_mean, double *err_m
  * one small device->host copy (error sums + flags) per iteration. */
 extern "C" int tcgpu_regularise_sph_particles(tcgpu_ctx *c, int max_iter, tcgpu_iterlog *log, int32_t *nlog_out)
 {
+    tc_loop_guard guard_(c);
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int it = -1, nlog = 0;
@@ -1052,6 +1107,7 @@ extern "C" int tcgpu_regularise_sph_particles(tcgpu_ctx *c, int max_iter, tcgpu_
 
 extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *bfld)
 {
+    tc_loop_guard guard_(c);
     if (!c || !apot || !bfld || c->n <= 0) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int rc = present(c);                          /* `apot` is in the order the caller sees */

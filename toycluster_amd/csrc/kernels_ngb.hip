@@ -848,7 +848,7 @@ __device__ __forceinline__ void density_one(const tc_density_args &a, int i, con
     const float4 pi = a.k.pos4[i];
     tc_dstate d;
     if (!density_init(a, i, d)) return;
-    const float rmax = a.k.margin_on ? tc_margin_radius(a.hsml_in[i], pi.w, a.k.boxsize) : HUGE_VALF;
+    const float rmax = a.k.margin_on ? tc_margin_radius(a.hsml_in[i], pi.w, a.k.boxsize, a.k.margin_widen) : HUGE_VALF;
     density_loop(a, i, pi.x, pi.y, pi.z, rl, idx, TC_IDXCAP, st, d, rmax);
     density_store(a, i, d);
 }
@@ -906,6 +906,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->own = c->nranks > 1 ? c->own_list : nullptr;
     k->lmin_tab = c->lmin_tab;
     k->margin_on = !c->local_full;
+    k->margin_widen = c->margin_widen;
     k->work_ctr = c->work_ctr;
     k->ablate = c->ablate;
 }
@@ -1337,7 +1338,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     }
 
     if (finite && !d.ok && isfinite(d.hsml)) {
-        const float rmax = k.margin_on ? tc_margin_radius(da.hsml_in[i], pi.w, k.boxsize) : HUGE_VALF;
+        const float rmax = k.margin_on ? tc_margin_radius(da.hsml_in[i], pi.w, k.boxsize, k.margin_widen) : HUGE_VALF;
         density_loop(da, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d, rmax);
     }
     if (finite) density_store<STATS>(da, i, d);

@@ -11,6 +11,7 @@
  * One thread per particle, 16-byte coalesced accesses on float4 positions.
  */
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/rocprim.hpp>
 #include "tc_ctx.h"
 
@@ -26,58 +27,145 @@
  * level.  Both sides pad like the cell-table query does (query_setup in kernels_ngb.hip), so every particle a
  * permitted query can accept is in the set; queries beyond the margin radius are refused by the solver kernels
  * and the pass is repeated (api.hip). */
+__device__ __forceinline__ size_t tc_sum_bit(size_t x, size_t y, size_t z)      /* bit of a level-TC_LS cell */
+{
+    return (((x << TC_LS) + y) << TC_LS) + z;
+}
+
+/* All 64 lanes mark the cells [c0, c0 + n) (unwrapped coordinates, periodic) of level L -- in the pyramid, or in the
+ * coarse summary when imask is the summary and off = 0.  Arguments are wave-uniform. */
+__device__ __forceinline__ void tc_mark_box(uint32_t *__restrict__ bits, int L, size_t off, const int c0[3], const int n[3])
+{
+    const int nL = 1 << L;
+    const int ncell = n[0] * n[1] * n[2];
+    for (int t = threadIdx.x & 63; t < ncell; t += 64) {
+        const int iz = t % n[2], iy = (t / n[2]) % n[1], ix = t / (n[2] * n[1]);
+        const size_t x = (size_t)((c0[0] + ix) & (nL - 1)), y = (size_t)((c0[1] + iy) & (nL - 1)),
+                     z = (size_t)((c0[2] + iz) & (nL - 1));
+        const size_t bit = off + ((((x << L) + y) << L) + z);
+        const uint32_t m = 1u << (bit & 31);
+        /* test first: thousands of waves mark the same few words, and same-address atomics serialise */
+        if (!(bits[bit >> 5] & m)) atomicOr(&bits[bit >> 5], m);
+    }
+}
+
+/* One wavefront per 64 consecutive own particles.
+ * Fine levels (where nearly all particles are): the 64 particles are neighbours along the Peano curve and their
+ * balls overlap almost completely -- the wave marks the cells of the common bounding box of the 64 balls once,
+ * with the largest radius of the wave: about one mark per particle instead of up to 125.
+ * Coarse levels (the few particles of the outskirts, whose cells are a sizeable part of the box, so that a
+ * bounding box would claim far too much) and waves of mixed levels: ball by ball, the 64 lanes sharing the cells
+ * of one ball.  Either way the level-TC_LS summary is marked for the same region. */
 __global__ __launch_bounds__(TB) void k_mark_interest(const float4 *__restrict__ gpos4, const float *__restrict__ ghsml,
                                                       int lo, int hi, double box, double box_mant, int box_exp,
-                                                      double level_scale, int level_shift, int lmax, int lp_max,
-                                                      uint32_t *__restrict__ imask, int *__restrict__ lvl_range)
+                                                      double level_scale, int level_shift, int lmax, int lp_max, int widen,
+                                                      uint32_t *__restrict__ imask, uint32_t *__restrict__ isum,
+                                                      int *__restrict__ lvl_range)
 {
-    int g = lo + blockIdx.x * TB + threadIdx.x;
-    if (g >= hi) return;
-    const float4 p = gpos4[g];
-    const float h0 = ghsml[g];
-    const float rg = tc_margin_radius(h0, p.w, box);
-    /* table levels the own queries of this pass can ask for: from the margin radius up to the first query */
-    const int la = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, rg);
-    const int lb = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, h0);
-    atomicMin(&lvl_range[0], la);
-    atomicMax(&lvl_range[1], lb);
-    /* marking level: cell edge s >= padded radius > s/2 (clamped to the pyramid) */
-    const double rp = (double)rg * (1.0 + 1e-5) + box * 2e-6;
-    int L = 1;
-    if (rp < box) {
-        const int er = __builtin_amdgcn_frexp_exp(rp) - 1;
-        const double mr = 2 * __builtin_amdgcn_frexp_mant(rp);
-        L = box_exp - er - (box_mant < mr ? 1 : 0);              /* floor(log2(box / rp)) */
+    const int g = lo + blockIdx.x * TB + threadIdx.x;
+    const bool act = g < hi;
+    const int lane = threadIdx.x & 63;
+    float4 p = make_float4(0, 0, 0, 0);
+    float h0 = 0, rg = 0;
+    int la = TC_MAX_LEVEL + 1, lb = 0;
+    if (act) {
+        p = gpos4[g];
+        h0 = ghsml[g];
+        rg = tc_margin_radius(h0, p.w, box, widen);
+        /* table levels the own queries of this pass can ask for: from the margin radius up to the first query */
+        la = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, rg);
+        lb = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, h0);
     }
-    if (L < 1) L = 1;
-    if (L > lp_max) L = lp_max;
-    const int nL = 1 << L;
-    const double inv_s = (double)nL / box;
-    int c0[3], nc[3];
-    const float xs[3] = {p.x, p.y, p.z};
-    for (int d = 0; d < 3; d++) {
-        int a = (int)floor(((double)xs[d] - rp) * inv_s), b = (int)floor(((double)xs[d] + rp) * inv_s);
-        int n = b - a + 1;
-        if (n >= nL) { n = nL; a = 0; }
-        c0[d] = a; nc[d] = n;
+    for (int o = 32; o > 0; o >>= 1) {
+        la = min(la, __shfl_xor(la, o));
+        lb = max(lb, __shfl_xor(lb, o));
     }
-    const size_t off = tc_level_offset(L);
-    for (int ix = 0; ix < nc[0]; ix++)
-        for (int iy = 0; iy < nc[1]; iy++)
-            for (int iz = 0; iz < nc[2]; iz++) {
-                const size_t x = (size_t)((c0[0] + ix) & (nL - 1)), y = (size_t)((c0[1] + iy) & (nL - 1)),
-                             z = (size_t)((c0[2] + iz) & (nL - 1));
-                const size_t bit = off + (x * nL + y) * nL + z;
-                const uint32_t m = 1u << (bit & 31);
-                if (!(imask[bit >> 5] & m)) atomicOr(&imask[bit >> 5], m);
+    if (lane == 0 && la <= TC_MAX_LEVEL) {                   /* test first: same-address atomics of 30 000 waves serialise */
+        if (la < lvl_range[0]) atomicMin(&lvl_range[0], la);
+        if (lb > lvl_range[1]) atomicMax(&lvl_range[1], lb);
+    }
+    /* marking level of a radius: cell edge s with rp/2 <= s < rp, i.e. a ball spans <= 5 cells per dimension
+     * (clamped to the pyramid); rp is the radius padded like the cell-table query (query_setup, kernels_ngb.hip) */
+    auto level_of = [&](double rp) {
+        int L = 1;
+        if (rp < box) {
+            const int er = __builtin_amdgcn_frexp_exp(rp) - 1;
+            const double mr = 2 * __builtin_amdgcn_frexp_mant(rp);
+            L = box_exp - er - (box_mant < mr ? 1 : 0) + 1;      /* floor(log2(box / rp)) + 1 */
+        }
+        if (L < 1) L = 1;
+        if (L > lp_max) L = lp_max;
+        return L;
+    };
+    /* cells of level L overlapped by the ball (q, rp): first cell and count per dimension (whole ring if it wraps round) */
+    auto ball_cells = [&](float qx, float qy, float qz, double rp, int L, int c0[3], int n[3]) {
+        const int nL = 1 << L;
+        const double inv_s = (double)nL / box;
+        const float xs[3] = {qx, qy, qz};
+        for (int d = 0; d < 3; d++) {
+            const int a = (int)floor(((double)xs[d] - rp) * inv_s), b = (int)floor(((double)xs[d] + rp) * inv_s);
+            c0[d] = a; n[d] = b - a + 1;
+            if (n[d] >= nL) { n[d] = nL; c0[d] = 0; }
+        }
+    };
+    const double rp_own = (double)rg * (1.0 + 1e-5) + box * 2e-6;
+    const int L_own = act ? level_of(rp_own) : 0;
+    float rmax = rg;
+    int Lmin = act ? L_own : 99, Lmax = L_own;
+    for (int o = 32; o > 0; o >>= 1) {
+        rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+        Lmin = min(Lmin, __shfl_xor(Lmin, o));
+        Lmax = max(Lmax, __shfl_xor(Lmax, o));
+    }
+    if (Lmax == 0) return;                                   /* a wave without own particles */
+    const int zero3[3] = {0, 0, 0};
+    (void)zero3;
+    if (Lmin >= 5 && Lmax - Lmin <= 1) {
+        const double rp = (double)rmax * (1.0 + 1e-5) + box * 2e-6;
+        const int L = level_of(rp), nL = 1 << L;
+        const double inv_s = (double)nL / box;
+        const float xs[3] = {p.x, p.y, p.z};
+        int w0[3], n[3];
+        bool compact = true;
+        for (int d = 0; d < 3; d++) {
+            int a = act ? (int)floor(((double)xs[d] - rp) * inv_s) : (1 << 30);
+            int b = act ? (int)floor(((double)xs[d] + rp) * inv_s) : -(1 << 30);
+            for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
+            w0[d] = a; n[d] = b - a + 1;
+            if (n[d] > 8) compact = false;                   /* a ball spans <= 5 cells; a compact wave adds one or two */
+        }
+        if (compact) {
+            tc_mark_box(imask, L, tc_level_offset(L), w0, n);
+            int s0[3], sn[3];                                /* the same box in summary cells (L >= 5 > TC_LS) */
+            for (int d = 0; d < 3; d++) {
+                const int a = w0[d] >> (L - TC_LS), b = (w0[d] + n[d] - 1) >> (L - TC_LS);
+                s0[d] = a; sn[d] = b - a + 1;
             }
+            tc_mark_box(isum, TC_LS, 0, s0, sn);
+            return;
+        }
+    }
+    /* ball by ball */
+    uint64_t todo = __ballot(act);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float qx = __shfl(p.x, l), qy = __shfl(p.y, l), qz = __shfl(p.z, l);
+        const double rp = __shfl(rp_own, l);
+        const int L = __shfl(L_own, l);
+        int c0[3], n[3];
+        ball_cells(qx, qy, qz, rp, L, c0, n);
+        tc_mark_box(imask, L, tc_level_offset(L), c0, n);
+        ball_cells(qx, qy, qz, rp, TC_LS, c0, n);
+        tc_mark_box(isum, TC_LS, 0, c0, n);
+    }
 }
 
 /* is particle p inside the interest mask?  (orphans -- a coordinate == boxsize, see k_cells -- always are: every
  * query that touches the periodic boundary tests them by brute force) */
 struct tc_in_mask {
     const float4 *gpos4;
-    const uint32_t *imask;
+    const uint32_t *imask, *isum;
     double box;
     int lp_max;
     __device__ bool operator()(uint32_t g) const
@@ -86,7 +174,12 @@ struct tc_in_mask {
         uint64_t X[3];
         tc_scaled_coords(p.x, p.y, p.z, box, X);
         if (((X[0] | X[1] | X[2]) >> 63) != 0) return true;
-        for (int L = 1; L <= lp_max; L++) {
+        {                                                     /* fast reject: nothing marked in or above this coarse cell */
+            const int sh = 63 - TC_LS;
+            const size_t sb = tc_sum_bit((size_t)(X[2] >> sh), (size_t)(X[0] >> sh), (size_t)(X[1] >> sh));
+            if (!(isum[sb >> 5] & (1u << (sb & 31)))) return false;
+        }
+        for (int L = lp_max; L >= 1; L--) {
             const int sh = 63 - L;
             const size_t nL = (size_t)1 << L;
             const size_t bit = tc_level_offset(L) + (((size_t)(X[2] >> sh) * nL) + (size_t)(X[0] >> sh)) * nL + (size_t)(X[1] >> sh);
@@ -119,13 +212,14 @@ int tc_launch_mark_interest(tcgpu_ctx *c)
     const size_t nbits = tc_level_offset(c->lp_max + 1);
     int e2 = 0;
     const double mant = 2 * frexp(c->par.boxsize, &e2);
-    const int init[2] = {TC_MAX_LEVEL + 1, 0};
+    const int init[8] = {TC_MAX_LEVEL + 1, 0, 0, 0, 0, 0, 0, 0};
     TC_HIP(c, hipMemsetAsync(c->imask, 0, (nbits / 32 + 1) * sizeof(uint32_t), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->isum, 0, ((size_t)1 << (3 * TC_LS)) / 8, c->stream));
     TC_HIP(c, hipMemcpyAsync(c->lvl_range, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     if (hi > lo)
         k_mark_interest<<<(unsigned)((hi - lo + TB - 1) / TB), TB, 0, c->stream>>>(
             c->g_pos4[c->gcur], c->g_hsml[c->gcur], (int)lo, (int)hi, c->par.boxsize, mant, e2 - 1, c->level_scale,
-            c->level_shift, c->lmax, c->lp_max, c->imask, c->lvl_range);
+            c->level_shift, c->lmax, c->lp_max, c->margin_widen, c->imask, c->isum, c->lvl_range);
     TC_HIP(c, hipGetLastError());
     return 0;
 }
@@ -133,13 +227,14 @@ int tc_launch_mark_interest(tcgpu_ctx *c)
 /* lsel = ascending global indices of the particles inside the mask; *nloc their number (synchronises) */
 int tc_select_local(tcgpu_ctx *c, int64_t *nloc)
 {
-    tc_in_mask pred{c->g_pos4[c->gcur], c->imask, c->par.boxsize, c->lp_max};
+    tc_in_mask pred{c->g_pos4[c->gcur], c->imask, c->isum, c->par.boxsize, c->lp_max};
     auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), pred);
     size_t b = c->sel_tmp_bytes;
     hipError_t e = rocprim::select(c->sel_tmp, b, rocprim::counting_iterator<uint32_t>(0), flags, c->lsel, c->d_count,
                                    (size_t)c->n, c->stream);
     TC_HIP(c, e);
     int h[3] = {0, 0, 0};
+    tc_phase_end(c);                                          /* PH_LOCAL, begun by the caller: mark + select */
     TC_HIP(c, hipMemcpyAsync(&h[0], c->d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     TC_HIP(c, hipMemcpyAsync(&h[1], c->lvl_range, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     TC_HIP(c, hipStreamSynchronize(c->stream));

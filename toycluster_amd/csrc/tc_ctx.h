@@ -52,6 +52,7 @@ struct tc_dev_const {
     const uint32_t *own;          /* sharded contexts: local indices of the particles this GPU solves, ascending */
     int lmin_tab;                 /* coarsest level the cell table holds (queries are clamped to [lmin_tab, lmax]) */
     int margin_on;                /* sharded contexts: a query beyond tc_margin_radius() must not run (ghosts end there) */
+    int margin_widen;             /* ... with this many extra x1.23 retries allowed (pass being repeated) */
     int *work_ctr;                /* dynamic work queue: per XCD group (stride 16 ints) the next unassigned particle */
     int ablate;                   /* profiling only: 1 producer only, 2 +predicate, 3 no solver (results invalid) */
 };
@@ -132,6 +133,8 @@ struct tcgpu_ctx {
     size_t sel_tmp_bytes;
     int *d_count;                 /* device: selected count */
     int margin_retry;             /* passes repeated because a query left the ghost margin (diagnostic) */
+    int margin_widen;             /* extra x1.23 retries the current pass allows */
+    uint32_t *isum;               /* 8^TC_LS bits: coarse summary of the interest pyramid (fast reject) */
     int local_w_valid;            /* the w lane of the local positions is the current model hsml */
     int lmax_rm0, lmin_rm0;       /* mirrored level range of a full local set (per pass: clipped to lmin_tab) */
     double comm_bytes;            /* bytes received in collectives since the last reset */
@@ -246,18 +249,20 @@ TC_HD double tc_limbs_to_double(double l0, double l1, double l2, double unit)
 
 #define TC_ERR_SCALE 68719476736.0        /* 2^36: fixed-point unit of the exact density-error sum */
 
-/* deepest level of the interest pyramid (8^8 cells = 2 MB of bits) */
+/* deepest level of the interest pyramid (8^8 cells = 2 MB of bits) and the level of its coarse summary */
 #define TC_LP_MAX 8
+#define TC_LS 4
 
 /* Largest radius the kernels may query for a particle with carried smoothing length h0 and WVT hsml w (box
  * units) before a sharded pass must be repeated with more ghosts: the reference's first query (h0), its retry at
  * 1.23 h0 (src/sph.c:49-54), one more retry, and the sweep's ball w*box (src/wvt_relax.c:135).  The marking
  * kernel and the solver kernels evaluate this very function, so the ghost set provably covers every query that
- * is allowed to run. */
-TC_HD float tc_margin_radius(float h0, float w, double boxsize)
+ * is allowed to run.  `widen` more retries are allowed when a pass had to be repeated (api.hip). */
+TC_HD float tc_margin_radius(float h0, float w, double boxsize, int widen)
 {
     const float hb = (float)((double)h0 * 1.23);
-    const float h3 = (float)((double)hb * 1.23);
+    float h3 = (float)((double)hb * 1.23);
+    for (int q = 0; q < widen; q++) h3 = (float)((double)h3 * 1.23);       /* a repeated pass allows more retries */
     const float hw = (float)((double)w * boxsize);
     const float r = h3 > hw ? h3 : hw;
     return r * 1.000001f;
