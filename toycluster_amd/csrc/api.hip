@@ -1125,8 +1125,22 @@ extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *
      * does not survive the presentation, so it is rebuilt here from the converged smoothing lengths */
     if (!c->index_valid && (rc = build_local(c, !c->g_compact, 1, 0))) return rc;
     if ((rc = tc_launch_gather_rho_vhf(c))) return rc;
-    if ((rc = tc_launch_gather_apot(c))) return rc;
-    if ((rc = tc_launch_curl(c, l_bfld))) return rc;
+    /* Make_magnetic_field sets Ax = Ay = Az (magnetic_field.c:63-65): then A rides in the w lane of the positions
+     * and of the mirror, and the kernel reads no side array per neighbour; any other A takes the general path */
+    int a_in_w = 0;
+    if ((rc = tc_launch_gather_apot(c, &a_in_w))) return rc;
+    if (multi(c)) {                               /* every rank must run the same kernel: agree on the flag */
+        double *buf = tc_pass_scalars(c) + 40;
+        const double mine = a_in_w ? 0.0 : 1.0;
+        TC_HIP(c, hipMemcpyAsync(buf, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if ((rc = allreduce_scalars(c, buf, 0, 1))) return rc;
+        double any = 0;
+        TC_HIP(c, hipMemcpyAsync(&any, buf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        a_in_w = any == 0.0;
+    }
+    if ((rc = tc_launch_mirror(c))) return rc;
+    if ((rc = tc_launch_curl(c, l_bfld, a_in_w))) return rc;
     if ((rc = tc_launch_scatter_bfld(c, l_bfld))) return rc;
     if (multi(c)) {
         tc_phase_begin(c, PH_COMM);

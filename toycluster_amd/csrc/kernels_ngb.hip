@@ -1408,10 +1408,15 @@ struct tc_curl_args {
     const float *hsml, *rho, *vhf;
     const float *apot;     /* 3n */
     float *bfld;           /* 3n */
+    uint32_t *ovf_list;    /* particles whose ball holds >= NGBMAX neighbours: solved by k_curl_slow afterwards */
+    int *ovf_count;
+    int ovf_cap;
+    int *flags;
 };
 
-/* src/sph.c:224-295 for particle i */
-__device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t *idx)
+/* src/sph.c:224-295 for particle i, pair by pair under the candidate predicate: the fall-back for a ball that
+ * overflows NGBMAX (the reference then truncates its list, src/tree.c:91-92) */
+__device__ __forceinline__ void curl_one_slow(const tc_curl_args &a, int i, uint32_t *idx)
 {
     const uint32_t idxcap = TC_IDXCAP;
     const int lane = lane_id();
@@ -1479,15 +1484,160 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
     }
 }
 
-__global__ __launch_bounds__(TBN) void k_curl(tc_curl_args a)
+
+/* src/sph.c:224-295 for particle i.  Same structure as the sweep of the fused kernel: candidates come as runs of
+ * the row-major mirror where the ball is interior (stream_rows) or cell by cell, the f32 predicate of the
+ * reference's ball query (src/tree.c:67-89) picks the hits, hits are compacted into an LDS ring of indices, and
+ * the f64 pair term -- separation, W', Price (2010) eq. 79 -- is evaluated 64 hits at a time on full waves. */
+template <bool AW>     /* AW: the three components of A are equal and ride in the w lane of the positions (magnetic_field.c:63-65) */
+__device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t *idx, uint32_t *ring, const tc_stage &st)
+{
+    const int lane = lane_id();
+    const tc_dev_const &k = a.k;
+    const float4 pv = k.pos4[i];
+    const float xi = U(pv.x), yi = U(pv.y), zi = U(pv.z);
+    const float hq = U(a.hsml[i]);
+    const float hq2 = hq * hq;
+    const double hsml = hq, rho_i = a.rho[i], vhf = a.vhf[i];
+    const double ax = a.apot[3 * (size_t)i], ay = a.apot[3 * (size_t)i + 1], az = a.apot[3 * (size_t)i + 2];
+    const double norm_h4 = TC_WC6_NORM / (double)(hq * hq * hq * hq) * -22.0;
+    const double wfac = -k.mpart / rho_i * vhf;             /* -m/rho_i * varHsmlFac (src/sph.c:282), dwk/r per pair */
+    tc_fdiv fd = tc_fdiv_setup(hq);
+    fd.exact_div = U(fd.exact_div);
+
+    const int qL = query_level(k, hq);
+    const double ext = (double)hq * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge_at(k, qL);
+    const bool wrap = U((int)!((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
+                               && (double)yi <= k.boxsize - ext && (double)zi >= ext && (double)zi <= k.boxsize - ext)) != 0;
+    const bool fast = U((int)(!wrap && k.mirror != nullptr && qL <= k.lmax_rm && qL >= k.lmin_rm)) != 0;
+    const tc_gpos vmirror = vgpr_pos(k.mirror);
+
+    double b0 = 0, b1 = 0, b2 = 0;
+    int cnt = 0, scnt = 0, head = 0;
+    auto convert = [&](auto ftag, int nvalid) {
+        constexpr bool F = decltype(ftag)::value;
+        wave_lds_fence();
+        const int sl = (head + lane) & (TC_STAGE - 1);
+        const bool valid = lane < nvalid;
+        float4 pj;
+        uint32_t jp = 0;
+        if (AW) {                                                          /* staged positions, A_j in the w lane: no loads here */
+            pj = make_float4(st.x[sl], st.y[sl], st.z[sl], st.w[sl]);
+        } else {
+            const uint32_t j = valid ? ring[sl] : (F ? 0u : (uint32_t)i);
+            pj = F ? ld4(vmirror, j) : k.pos4[j];
+            jp = F ? k.mirror_idx[valid ? j : 0u] : j;                     /* particle index: A lives in particle order */
+        }
+        if (valid) {
+            double dx = (double)xi - (double)pj.x, dy = (double)yi - (double)pj.y, dz = (double)zi - (double)pj.z;
+            if (!F && wrap) {
+                if (dx > k.boxhalf) dx -= k.boxsize;
+                if (dx < -k.boxhalf) dx += k.boxsize;
+                if (dy > k.boxhalf) dy -= k.boxsize;
+                if (dy < -k.boxhalf) dy += k.boxsize;
+                if (dz > k.boxhalf) dz -= k.boxsize;
+                if (dz < -k.boxhalf) dz += k.boxsize;
+            }
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (!(r2 > hsml * hsml)) {          /* src/sph.c:271-272 (a coincident particle gives 0/0 = NaN there and here) */
+                const double r = tc_sqrt_f64_lean(r2);
+                /* sph_kernel_derivative_WC6 (src/sph.c:434-440): u = r/h in f32, t = (double)(1-u), trailing polynomial in f32 */
+                const float u = tc_fdiv_apply(fd, (float)r);
+                const double t = (double)(1 - u);
+                const double t2 = t * t, t4 = t2 * t2, t7 = t4 * t2 * t;
+                const float polyf = __builtin_fmaf(u, __builtin_fmaf(u, 16.0f, 7.0f), 1.0f);
+                const double dwk = (double)(float)(norm_h4 * t7 * (double)u * (double)polyf);
+                const double weight = wfac * dwk * tc_rcp_f64_lean(r);
+                if (AW) {
+                    const double wdA = weight * (ax - (double)pj.w);         /* dAx = dAy = dAz */
+                    b0 = fma(wdA, dz - dy, b0);
+                    b1 = fma(wdA, dx - dz, b1);
+                    b2 = fma(wdA, dy - dx, b2);
+                } else {
+                    const double dAx = ax - (double)a.apot[3 * (size_t)jp];
+                    const double dAy = ay - (double)a.apot[3 * (size_t)jp + 1];
+                    const double dAz = az - (double)a.apot[3 * (size_t)jp + 2];
+                    b0 = fma(weight, dz * dAy - dy * dAz, b0);
+                    b1 = fma(weight, dx * dAz - dz * dAx, b1);
+                    b2 = fma(weight, dy * dAx - dx * dAy, b2);
+                }
+            }
+        }
+        head = U((head + 64) & (TC_STAGE - 1));
+        wave_lds_fence();
+    };
+    auto gather = [&](auto ftag, uint32_t j, float4 p, bool act) -> bool {
+        constexpr bool F = decltype(ftag)::value;
+        const float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, F ? false : wrap);
+        const bool hit = act && (r2 < hq2);
+        uint64_t m = tc_ballot(hit);
+        cnt = U(cnt + (int)__popcll(m));
+        bool use = hit;
+        if (tc_ballot(hit && r2 == 0.0f)) {                    /* the particle itself is not a neighbour (src/sph.c:243-244) */
+            const bool self = hit && r2 == 0.0f && (F ? k.mirror_idx[j] == (uint32_t)i : j == (uint32_t)i);
+            use = hit && !self;
+            m = tc_ballot(use);
+        }
+        if (use) {
+            const int sl = (head + scnt + mask_rank(m)) & (TC_STAGE - 1);
+            if (AW) { st.x[sl] = p.x; st.y[sl] = p.y; st.z[sl] = p.z; st.w[sl] = p.w; }
+            else ring[sl] = j;
+        }
+        scnt = U(scnt + (int)__popcll(m));
+        if (scnt >= 64) { convert(ftag, 64); scnt = U(scnt - 64); }
+        return cnt >= TC_NGBMAX;
+    };
+    if (fast) {
+        const std::true_type F;
+        stream_rows(k, xi, yi, zi, hq, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
+        if (cnt < TC_NGBMAX && scnt > 0) convert(F, scnt);
+    } else {
+        const std::false_type F;
+        stream_candidates(k, xi, yi, zi, hq, idx, TC_IDXCAP, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
+        if (cnt < TC_NGBMAX && scnt > 0) convert(F, scnt);
+    }
+    if (cnt >= TC_NGBMAX) {                                    /* list truncation semantics: left to k_curl_slow */
+        if (lane == 0) {
+            const int slot = atomicAdd(a.ovf_count, 1);
+            if (slot < a.ovf_cap) a.ovf_list[slot] = (uint32_t)i;
+            else atomicOr(&a.flags[3], 1);
+        }
+        return;
+    }
+    b0 = wsum(b0); b1 = wsum(b1); b2 = wsum(b2);
+    if (lane == 0) {
+        a.bfld[3 * (size_t)i] = (float)b0;
+        a.bfld[3 * (size_t)i + 1] = (float)b1;
+        a.bfld[3 * (size_t)i + 2] = (float)b2;
+    }
+}
+
+template <bool AW>
+__global__ __launch_bounds__(TBN, 4) void k_curl(tc_curl_args a)
+{
+    __shared__ __align__(16) uint32_t lds_idx[WPB * TC_IDXCAP];
+    __shared__ __align__(16) float lds_ring[WPB * 4 * TC_STAGE];
+    const int wave = threadIdx.x >> 6;
+    uint32_t *idx = lds_idx + (size_t)wave * TC_IDXCAP;
+    tc_stage st;
+    st.x = lds_ring + (size_t)wave * 4 * TC_STAGE;
+    st.y = st.x + TC_STAGE; st.z = st.y + TC_STAGE; st.w = st.z + TC_STAGE;
+    uint32_t *ring = reinterpret_cast<uint32_t *>(st.x);
+    work_queue(a.k, [&](int i) { curl_one<AW>(a, i, idx, ring, st); });
+}
+
+/* the literal path for the particles k_curl set aside (normally none); the list length is read on the device */
+__global__ __launch_bounds__(TBN) void k_curl_slow(tc_curl_args a)
 {
     __shared__ __align__(16) uint32_t lds_idx[WPB * TC_IDXCAP];
     const int wave = threadIdx.x >> 6;
     uint32_t *idx = lds_idx + (size_t)wave * TC_IDXCAP;
-    work_queue(a.k, [&](int i) { curl_one(a, i, idx); });
+    int n = *a.ovf_count;
+    if (n > a.ovf_cap) n = a.ovf_cap;
+    for (int t = blockIdx.x * WPB + wave; t < n; t += gridDim.x * WPB) curl_one_slow(a, (int)a.ovf_list[t], idx);
 }
 
-int tc_launch_curl(tcgpu_ctx *c, float *l_bfld)
+int tc_launch_curl(tcgpu_ctx *c, float *l_bfld, int a_in_w)
 {
     tc_curl_args a;
     tc_fill_const(c, &a.k);
@@ -1496,11 +1646,18 @@ int tc_launch_curl(tcgpu_ctx *c, float *l_bfld)
     a.vhf = c->vhf;
     a.apot = c->l_apot;
     a.bfld = l_bfld;
+    a.ovf_list = reinterpret_cast<uint32_t *>(c->ngb_buf);
+    a.ovf_count = c->d_count + 3;
+    a.ovf_cap = (int)c->cap;
+    a.flags = c->flags;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     tc_phase_begin(c, PH_CURL);
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
-    k_curl<<<grid_for(c, nloc, k_curl), TBN, 0, c->stream>>>(a);
+    TC_HIP(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(int), c->stream));
+    if (a_in_w) k_curl<true><<<grid_for(c, nloc, k_curl<true>), TBN, 0, c->stream>>>(a);
+    else k_curl<false><<<grid_for(c, nloc, k_curl<false>), TBN, 0, c->stream>>>(a);
+    k_curl_slow<<<256, TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;

@@ -1033,11 +1033,32 @@ int tc_launch_gather_rho_vhf(tcgpu_ctx *c)
     return 0;
 }
 
-int tc_launch_gather_apot(tcgpu_ctx *c)
+/* A in local order; its first component also into the w lane of the local positions, with a flag raised when
+ * the three components differ anywhere (then the curl reads l_apot instead) */
+__global__ __launch_bounds__(TB) void k_gather_apot(int n, const uint32_t *__restrict__ lg, const float *__restrict__ in,
+                                                    float *__restrict__ out, float4 *__restrict__ pos4, int *__restrict__ differ)
+{
+    int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const size_t g = lg[i];
+    const float a0 = in[3 * g], a1 = in[3 * g + 1], a2 = in[3 * g + 2];
+    out[3 * (size_t)i] = a0; out[3 * (size_t)i + 1] = a1; out[3 * (size_t)i + 2] = a2;
+    pos4[i].w = a0;
+    if (!(a0 == a1 && a1 == a2)) atomicOr(differ, 1);
+}
+
+int tc_launch_gather_apot(tcgpu_ctx *c, int *equal_components)
 {
     const int n = (int)c->nloc;
-    k_gather_rows3<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->lg, c->apot, c->l_apot);
+    TC_HIP(c, hipMemsetAsync(c->d_count + 2, 0, sizeof(int), c->stream));
+    k_gather_apot<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->lg, c->apot, c->l_apot, c->pos4, c->d_count + 2);
     TC_HIP(c, hipGetLastError());
+    int differ = 0;
+    TC_HIP(c, hipMemcpyAsync(&differ, c->d_count + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    TC_HIP(c, hipStreamSynchronize(c->stream));
+    *equal_components = !differ;
+    c->local_w_valid = 0;                     /* the w lane now holds A, not the WVT hsml */
+    c->mirror_valid = 0;
     return 0;
 }
 

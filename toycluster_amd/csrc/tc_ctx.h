@@ -298,14 +298,14 @@ int tc_launch_move(tcgpu_ctx *c);
 int tc_launch_flags_to_f64(tcgpu_ctx *c, double *d_out);   /* flags[0..3], flags[5] != 0 as five doubles */
 int tc_launch_commit_rhom(tcgpu_ctx *c);
 int tc_launch_gather_rho_vhf(tcgpu_ctx *c);     /* rho, vhf (local) = G values */
-int tc_launch_gather_apot(tcgpu_ctx *c);        /* l_apot[i] = apot[lg[i]] */
+int tc_launch_gather_apot(tcgpu_ctx *c, int *equal_components);   /* l_apot[i] = apot[lg[i]]; pos4.w = A if Ax == Ay == Az everywhere */
 int tc_launch_scatter_bfld(tcgpu_ctx *c, const float *l_bfld);
 /* neighbour kernels */
 int tc_launch_density(tcgpu_ctx *c);
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt);   /* fused density (+ unit-step WVT sums) */
 int tc_launch_apply_step(tcgpu_ctx *c, double step);  /* delta (G order) = step * ustep (local order) */
 int tc_launch_wvt(tcgpu_ctx *c, double step);
-int tc_launch_curl(tcgpu_ctx *c, float *l_bfld);
+int tc_launch_curl(tcgpu_ctx *c, float *l_bfld, int a_in_w);   /* a_in_w: pos4.w / mirror.w hold A (equal components) */
 int tc_launch_find_ngb(tcgpu_ctx *c, int ipart, float hsml);
 void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k);
 /* the rank's own index range of G */
