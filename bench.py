@@ -128,6 +128,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     g.phase_times(reset=True)
+    g.comm_bytes(reset=True)
 
     barrier()
     t0 = time.perf_counter()
@@ -141,6 +142,8 @@ def main():
         dt = float(t.item())
 
     phases = g.phase_times()
+    recv_bytes = g.comm_bytes() / max(1, args.steps)
+    lset = g.local_set_info()
     dens_s, dens_launch = phases["density"]
     dens_avg = dens_s / max(1, dens_launch)
     n_local = (n_total + world - 1) // world
@@ -204,7 +207,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "2-cluster merger (Mass_Ratio 0.3125), %d SPH particles per GPU, "
                                    "WVT iterations (sort + density solve + sweep + move)" % args.particles_per_gpu,
-                       "particles_total": n_total, "parallelism": "peano-range shards x%d, RCCL all-gather" % world,
+                       "particles_total": n_total,
+                       "parallelism": "peano-range shards x%d: per-rank local set (own range + ghost shell) with its own "
+                                      "sort / cell table / mirror; one RCCL all-gather of positions (16 B/particle) and two "
+                                      "exact scalar all-reduces per iteration" % world,
+                       "rank0_local_set": lset, "rank0_recv_bytes_per_step": recv_bytes,
                        "err_mean_last": errs[-1][0], "err_max_last": errs[-1][1]},
             # k_iter is a gather/stencil kernel bound by the vector ALU, not by HBM: the
             # headline fraction is counted vector flops against the f64 vector peak; the HBM fraction of its

@@ -98,6 +98,13 @@ __device__ __forceinline__ double min_f64(double a, double b)
     return r;
 }
 
+__device__ __forceinline__ double max_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 /* wave-uniform copy of a double (lets the compiler keep dependent control flow scalar) */
 __device__ __forceinline__ double bcast0(double v)
 {
@@ -714,10 +721,12 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         if (fabs(upper - lower) < 1e-4) { hsml *= 1.26; break; }
 
         if (ngbDev < 0.5 * TC_DESNNGB) {
-            double omega = (1 + dRhodHsml * hsml / (3 * rho));
-            double fac = 1 - (wkNgb - TC_DESNNGB) / (3 * wkNgb * omega);
-            fac = fmin(1.24, fac);
-            fac = fmax(1 / 1.24, fac);
+            /* src/sph.c:176-183; both quotients have operands in the normal range (rho, wkNgb > 0 here): the
+             * unscaled divide returns the IEEE bits (tc_lean.h); single-instruction min / max as above */
+            double omega = (1 + tc_div_f64_lean(dRhodHsml * hsml, 3 * rho));
+            double fac = 1 - tc_div_f64_lean(wkNgb - TC_DESNNGB, 3 * wkNgb * omega);
+            fac = min_f64(1.24, fac);
+            fac = max_f64(1 / 1.24, fac);
             hsml *= fac;
         } else {
             if (wkNgb > TC_DESNNGB) upper = hsml;

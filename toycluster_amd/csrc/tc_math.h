@@ -51,11 +51,15 @@ TC_HD void tc_scaled_coords(float px, float py, float pz, double box, uint64_t X
 }
 
 /* Skilling's transpose <-> Hilbert transform, "inverse undo" + Gray encode
- * (peano.c:140-177).  Works in place on the {y,z,x} transpose array. */
+ * (peano.c:140-177).  Works in place on the {y,z,x} transpose array.
+ * The reference runs the undo loop over q = 2^63 ... 2.  The step at q only rewrites bits BELOW q, and the Gray
+ * encode only mixes a bit with HIGHER bits, so bits 63..21 of the result -- all the key uses (peano.c:181-200:
+ * 43 triplets from bit 63 down to bit 21) -- are final after the step q = 2^22: the loop stops there.  Bits
+ * below 21 of the returned words are NOT the reference's (nobody reads them). */
 TC_HD void tc_hilbert_transpose(uint64_t X[3])
 {
     uint64_t X0 = X[0], X1 = X[1], X2 = X[2];
-    for (uint64_t q = 1ULL << 63; q > 1; q >>= 1) {
+    for (uint64_t q = 1ULL << 63; q > (1ULL << 21); q >>= 1) {
         const uint64_t P = q - 1;
         if (X0 & q) X0 ^= P;
         if (X1 & q) {
