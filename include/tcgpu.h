@@ -126,14 +126,15 @@ int tcgpu_build_neighbour_index(tcgpu_ctx *ctx);
 /* src/tree.c:113-121 evaluated for every particle (the first-pass hsml guess, before doubling). */
 int tcgpu_guess_hsml(tcgpu_ctx *ctx, float *guess_out);
 /* One WVT sweep (src/wvt_relax.c:106-214) at the given step on the current order.
- * hsml_wvt[n] / delta[3n] may be NULL; move!=0 applies src/wvt_relax.c:193-213. */
+ * hsml_wvt[n] / delta[3n] may be NULL (and must be on sharded contexts: own-range arrays); move!=0 applies
+ * src/wvt_relax.c:193-213. */
 int tcgpu_wvt_step(tcgpu_ctx *ctx, double step, float *hsml_wvt, float *delta, int move);
 /* First half of one loop body (src/wvt_relax.c:66-87): Find_sph_quantities() + the error sums.
  * One WVT "step" of the benchmark = tcgpu_density_error() + tcgpu_wvt_step(move=1). */
 int tcgpu_density_error(tcgpu_ctx *ctx, double *err_mean, double *err_max);
-/* Sharded contexts: after tcgpu_density_error() only hsml is exchanged between the ranks; rho and
- * varHsmlFac are complete on every rank after tcgpu_find_sph_quantities() or
- * tcgpu_regularise_sph_particles(). */
+/* Sharded contexts: the passes leave results in the rank's own index range; every call that returns or takes
+ * per-particle arrays (downloads, find_ngb, bfld, ...) first completes them on all ranks and brings the particles
+ * into Peano order ("presentation"), so it is COLLECTIVE: all ranks must make it, in the same order. */
 /* src/wvt_relax.c:25-225.  max_iter < 0 => NUMITER.  log has TCGPU_MAXLOG slots. */
 int tcgpu_regularise_sph_particles(tcgpu_ctx *ctx, int max_iter, tcgpu_iterlog *log, int32_t *nlog);
 /* src/sph.c:216-300.  apot: f32[3n] in the CURRENT order; bfld out f32[3n]. */
