@@ -256,6 +256,63 @@ def normalise_magnetic_field(model, pos, bfld, bfld_norm, r_sample_dm, sub_first
     return b, norm.value, cnt.value
 
 
+class OrcSubHalo(C.Structure):
+    _fields_ = [("Mtotal200", C.c_double), ("Mass200", C.c_double * 2), ("C_nfw", C.c_double), ("R200", C.c_double),
+                ("Rs", C.c_double), ("A_hernq", C.c_double), ("Rho0", C.c_double), ("Beta", C.c_double),
+                ("Rcore", C.c_double), ("Rcut", C.c_double), ("R_Sample", C.c_double * 2), ("Mass", C.c_double * 2),
+                ("Mtotal", C.c_double), ("MassCorrFac", C.c_double), ("D_CoM", C.c_double * 3),
+                ("Npart", C.c_longlong * 2), ("Have_Cuspy", C.c_int), ("Is_Stripped", C.c_int)]
+
+
+class OrcSubState(C.Structure):
+    _fields_ = [("Mpart", C.c_double * 2), ("Redshift", C.c_double), ("Mass_Ratio", C.c_double),
+                ("GravSofteningLength", C.c_double), ("Baryon_Fraction", C.c_double), ("UnitMass", C.c_double),
+                ("UnitDensity", C.c_double), ("Rho_crit0", C.c_double), ("OverdensityParameter", C.c_double),
+                ("Nhalos", C.c_int), ("Cuspy", C.c_int), ("SUBHOST", C.c_int), ("Seed", C.c_ushort * 3),
+                ("First", C.c_int), ("SubNhalos", C.c_int), ("Mtotal", C.c_double), ("MassFraction", C.c_double),
+                ("SubNpart", C.c_longlong * 2)]
+
+
+def setup_substructure(setup, seed, subhost=0):
+    """Setup_Substructure (src/substructure.c:31-109) restated in oracle/tc_oracle_sub.c, run on the state a native
+    set-up (toycluster_amd.hostio.Setup BEFORE its own substructure step) left behind.  `seed` = thread 0's erand48
+    state.  Returns (state, [halo dicts])."""
+    L = lib()
+    halos = (OrcSubHalo * 128)()
+    for i in range(setup.nhalos):
+        h, o = setup.halo[i], halos[i]
+        o.Mtotal200, o.C_nfw, o.R200, o.Rs, o.A_hernq = h.mtotal200, h.c_nfw, h.r200, h.rs, h.a_hernq
+        o.Rho0, o.Beta, o.Rcore, o.Rcut, o.Mtotal, o.MassCorrFac = h.rho0, h.beta, h.rcore, h.rcut, h.mtotal, h.mass_corr_fac
+        for k in range(2):
+            o.Mass200[k], o.R_Sample[k], o.Mass[k], o.Npart[k] = h.mass200[k], h.r_sample[k], h.mass[k], h.npart[k]
+        for k in range(3):
+            o.D_CoM[k] = h.d_com[k]
+        o.Have_Cuspy, o.Is_Stripped = h.have_cuspy, h.is_stripped
+    st = OrcSubState()
+    st.Mpart[0], st.Mpart[1] = setup.mpart[0], setup.mpart[1]
+    st.Redshift, st.Mass_Ratio = setup.par.redshift, setup.par.mass_ratio
+    st.GravSofteningLength, st.Baryon_Fraction = setup.grav_softening, setup.par.baryon_fraction
+    st.UnitMass, st.UnitDensity = setup.unit_mass, setup.unit_mass / setup.unit_length ** 3
+    st.Rho_crit0 = 3.0 / 8.0 / np.pi / 6.673e-8 * setup.h0_cgs ** 2       # src/cosmo.c:20, GSL's cgs G
+    st.OverdensityParameter = setup.delta
+    st.Nhalos, st.Cuspy, st.SUBHOST = setup.nhalos, setup.par.cuspy, subhost
+    for k in range(3):
+        st.Seed[k] = seed[k]
+    L.orc_setup_substructure.argtypes = [C.POINTER(OrcSubState), C.POINTER(OrcSubHalo)]
+    rc = L.orc_setup_substructure(C.byref(st), halos)
+    if rc:
+        raise RuntimeError("orc_setup_substructure: %d" % rc)
+    fields = [f[0] for f in OrcSubHalo._fields_]
+    out = []
+    for i in range(st.Nhalos):
+        d = {}
+        for f in fields:
+            v = getattr(halos[i], f)
+            d[f] = list(v) if hasattr(v, "__len__") else v
+        out.append(d)
+    return st, out
+
+
 def format_log_line(l):
     """The reference's per-iteration line, wvt_relax.c:91-92."""
     return "   #%02d: Err max=%3g mean=%03g diff=%03g step=%g" % (

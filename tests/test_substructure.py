@@ -92,3 +92,41 @@ def test_sampling_with_subhalos_puts_every_particle_in_its_halo():
         p = pos[off[i]:off[i + 1]].astype(np.float64) - s.boxsize / 2 - np.array(s.halo[i].d_com)
         if len(p):
             assert np.sqrt((p * p).sum(axis=1)).max() <= s.halo[i].r_sample[0] * (1 + 1e-5)
+
+
+@pytest.mark.parametrize("overrides", [{"ntotal": 600000}, {"ntotal": 4000000, "mass_ratio": 0.3125},
+                                       {"ntotal": 2000000, "mass_ratio": 0.3125, "cuspy": 1}])
+def test_subhalo_table_matches_oracle_restatement(overrides):
+    """the host code's Setup_Substructure (toycluster_amd/host/tc_setup.c) against the oracle's
+    statement-by-statement restatement of src/substructure.c:31-553 (oracle/tc_oracle_sub.c) on the same set-up state
+    and the same erand48 stream: the same number of subhalos, the same stream position afterwards, and every table
+    entry equal -- bit for bit where no quadrature is involved (masses, positions, radii, concentrations, rho0),
+    to 1e-8 where the gas mass inside R_Sample is integrated (two independent integrators, neither of them GSL's).
+    Parity unpinned: the reference's default build does not compile this file and holds no fixture for it."""
+    import ctypes as C
+    from oracle import oracle as O
+    par = os.path.join(GOLDEN, "cluster.par") if "GOLDEN" in globals() else os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cluster.par")
+    s = hostio.setup_system(par, overrides)
+    seed = (C.c_ushort * 3)()
+    L = hostio._lib()
+    L.tc_thread_seed.argtypes = [C.c_int, C.c_void_p]
+    L.tc_thread_seed(0, seed)
+    st, tab = O.setup_substructure(s, tuple(seed))
+    s2 = hostio.setup_system(par, overrides)
+    seed_after = hostio.setup_substructure(s2, 0)
+    assert st.Nhalos == s2.nhalos and st.SubNhalos == s2.sub_nhalos and st.First == s2.sub_first
+    assert tuple(st.Seed) == tuple(seed_after)                      # the same number of draws, rejections included
+    assert st.Mtotal == s2.sub_mtotal and st.MassFraction == s2.sub_mass_fraction
+    assert list(st.SubNpart) == list(s2.sub_npart)
+    assert st.Nhalos - st.First >= 5
+    for i in range(s2.nhalos):
+        h, t = s2.halo[i], tab[i]
+        exact = [("Mass200", list(h.mass200)), ("C_nfw", h.c_nfw), ("R200", h.r200), ("Rs", h.rs), ("A_hernq", h.a_hernq),
+                 ("Rho0", h.rho0), ("Beta", h.beta), ("Rcore", h.rcore), ("Rcut", h.rcut), ("R_Sample", list(h.r_sample)),
+                 ("MassCorrFac", h.mass_corr_fac), ("D_CoM", list(h.d_com)), ("Mtotal200", h.mtotal200),
+                 ("Have_Cuspy", h.have_cuspy), ("Is_Stripped", h.is_stripped), ("Npart", list(h.npart))]
+        for name, want in exact:
+            assert t[name] == want, (i, name, t[name], want)
+        assert t["Mass"][1] == h.mass[1]
+        assert t["Mass"][0] == pytest.approx(h.mass[0], rel=1e-8, abs=1e-12)
+        assert t["Mtotal"] == pytest.approx(h.mtotal, rel=1e-8)

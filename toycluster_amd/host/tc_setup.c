@@ -251,7 +251,7 @@ void tc_setup_to_model(const tc_setup *S, tcgpu_params *par, tcgpu_halo *halos)
 
 static double hernquist_density(double m, double a, double r)                  /* src/setup.c:715-718 */
 {
-    return m / (2 * PI) * a / (r * (r + a) * (r + a) * (r + a));
+    return m / (2 * PI) * a / (r * ((r + a) * (r + a) * (r + a)));             /* r * p3(r + a) */
 }
 
 static double sub_mass_function(const tc_setup *S, double m)                    /* src/substructure.c:471-482 */
@@ -261,7 +261,7 @@ static double sub_mass_function(const tc_setup *S, double m)                    
     const double mSub = m * S->unit_mass / MSOL2CGS;
     const double mHost = S->halo[S->subhost].mass200[1] * S->unit_mass / MSOL2CGS;
     const double x = mSub / mHost;
-    return mHost * sqrt(1 + z) * cc * Am * pow(mSub, alpha) * exp(-beta * x * x * x);
+    return mHost * sqrt(1 + z) * cc * Am * pow(mSub, alpha) * exp(-beta * (x * x * x));      /* p3(x) is one factor */
 }
 
 static double sub_number_density(const tc_setup *S, double r)                   /* src/substructure.c:495-500 */
@@ -283,11 +283,11 @@ static double sub_inverted_number_density(const tc_setup *S, double q)          
 
 static double nfw_mass(const tc_setup *S, double c_nfw, double rs, double r)    /* src/substructure.c:542-553 */
 {
-    const double delta_s = S->delta / 3 * c_nfw * c_nfw * c_nfw / (log(1 + c_nfw) - c_nfw / (1 + c_nfw));
+    const double delta_s = S->delta / 3 * (c_nfw * c_nfw * c_nfw) / (log(1 + c_nfw) - c_nfw / (1 + c_nfw));   /* p3() groups */
     const double rho_crit0 = 3. / 8. / PI / GRAV_CGS * S->h0_cgs * S->h0_cgs;  /* src/cosmo.c:20 */
     const double unit_density = S->unit_mass / (S->unit_length * S->unit_length * S->unit_length);
     const double rho_s = delta_s * rho_crit0 / unit_density;
-    return 4 * PI * rho_s * rs * rs * rs * (log((rs + r) / rs) - r / (rs + r));
+    return 4 * PI * rho_s * (rs * rs * rs) * (log((rs + r) / rs) - r / (rs + r));
 }
 
 static double nfw_scale_radius(const tc_setup *S, double c_nfw, double M_t, double r)   /* src/substructure.c:521-540 */
@@ -422,7 +422,7 @@ static void set_subhalo_properties(tc_setup *S, int i)                          
     if (i < 31 && (S->par.cuspy & (1 << i))) { h->rcore = h->rs / 9; h->have_cuspy = 1; }   /* src/setup.c:567-589 */
     else { h->rcore = h->rs / 3; h->have_cuspy = 0; }
     const double rc = h->rcore;
-    h->rho0 = h->mass200[0] / (4 * PI * rc * rc * rc) / (r200 / rc - atan(r200 / rc));
+    h->rho0 = h->mass200[0] / (4 * PI * (rc * rc * rc)) / (r200 / rc - atan(r200 / rc));
     h->mass[0] = 0;
     h->is_stripped = 1;
     if (r_i > r_strip) {
