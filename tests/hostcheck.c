@@ -30,3 +30,10 @@ float hc_density_model(float px, float py, float pz, double boxhalf, const tc_ha
 {
     return tc_density_model(px, py, pz, boxhalf, halo, nhalos);
 }
+
+/* the table-driven key the kernels use (csrc/tc_math.h::tc_peano_key_lut, table from tools/gen_hilbert_lut.py) */
+#include "../toycluster_amd/csrc/tc_hilbert_lut.h"
+void hc_peano_key_lut(float x, float y, float z, double box, uint64_t *hi, uint64_t *lo)
+{
+    tc_peano_key_lut(x, y, z, box, TC_HILBERT_LUT, hi, lo);
+}

@@ -22,6 +22,7 @@ def hc(tmp_path_factory):
     L = C.CDLL(so)
     f, d, u64 = C.c_float, C.c_double, C.c_uint64
     L.hc_peano_key.argtypes = [f, f, f, d, C.POINTER(u64), C.POINTER(u64)]
+    L.hc_peano_key_lut.argtypes = [f, f, f, d, C.POINTER(u64), C.POINTER(u64)]
     L.hc_common_levels.argtypes = [u64, u64, u64, u64]
     L.hc_fdiv.argtypes = [f, f]; L.hc_fdiv.restype = f
     L.hc_wc6.argtypes = [f, f]; L.hc_wc6.restype = f
@@ -42,6 +43,10 @@ def test_device_key_arithmetic_matches_oracle(hc):
         k = (hi.value << 64) | lo.value
         x, y, z = (float(np.float64(c) / box) for c in p)
         assert k == O.peano_key(x, y, z)
+        # the table-driven form the kernels run (24 orientations, two levels per look-up): the same 128 bits,
+        # coordinates on the box faces included
+        hc.hc_peano_key_lut(p[0], p[1], p[2], box, C.byref(hi), C.byref(lo))
+        assert ((hi.value << 64) | lo.value) == k
         keys.append(k)
     # shared Hilbert levels = floor(common leading key bits / 3)
     for a, b in zip(keys[:500], keys[1:501]):

@@ -14,8 +14,15 @@
 #include <cstdlib>
 #include <rocprim/rocprim.hpp>
 #include "tc_ctx.h"
+#include "tc_hilbert_lut.h"
 
 #define TB 256
+
+__device__ const unsigned short TC_HILBERT_LUT_DEV[TC_HILBERT_NSTATES * 64] = {
+#define TC_HILBERT_LUT_ROWS_ONLY
+#include "tc_hilbert_lut.h"
+#undef TC_HILBERT_LUT_ROWS_ONLY
+};
 
 /* ------------------------------------------------------------------ interest mask + local set
 
@@ -245,11 +252,21 @@ int tc_select_local(tcgpu_ctx *c, int64_t *nloc)
 
 /* ------------------------------------------------------------------ K1 keys (of the local set) */
 
+/* the orientation table of the Hilbert curve (tc_hilbert_lut.h, 3 KB) in LDS: per-lane indexed reads */
+__device__ __forceinline__ void load_hilbert_lut(unsigned short *lds)
+{
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES * 64 / 2; t += TB)
+        reinterpret_cast<uint32_t *>(lds)[t] = reinterpret_cast<const uint32_t *>(TC_HILBERT_LUT_DEV)[t];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(TB) void k_keys_local(const float4 *__restrict__ gpos4, const uint32_t *__restrict__ lsel,
                                                    int nloc, double box, uint32_t own_lo, uint32_t own_hi,
                                                    tc_u128 *__restrict__ key, uint32_t *__restrict__ idx,
                                                    tc_u128 *__restrict__ gkey, int *__restrict__ flags)
 {
+    __shared__ __align__(16) unsigned short lut[TC_HILBERT_NSTATES * 64];
+    load_hilbert_lut(lut);
     int i = blockIdx.x * TB + threadIdx.x;
     if (i >= nloc) return;
     const uint32_t g = lsel ? lsel[i] : (uint32_t)i;
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(TB) void k_keys_local(const float4 *__restrict__ gp
         p.x = p.y = p.z = 0;
     }
     uint64_t hi, lo;
-    tc_peano_key(p.x, p.y, p.z, box, &hi, &lo);
+    tc_peano_key_lut(p.x, p.y, p.z, box, lut, &hi, &lo);       /* src/peano.c:128-203, two levels per table look-up */
     const tc_u128 k = ((tc_u128)hi << 64) | lo;
     key[i] = k;
     idx[i] = (uint32_t)i;
@@ -271,6 +288,8 @@ __global__ __launch_bounds__(TB) void k_keys_local(const float4 *__restrict__ gp
 __global__ __launch_bounds__(TB) void k_keys_xyz(const double *__restrict__ xyz, int64_t n,
                                                  uint64_t *__restrict__ khi, uint64_t *__restrict__ klo)
 {
+    __shared__ __align__(16) unsigned short lut[TC_HILBERT_NSTATES * 64];
+    load_hilbert_lut(lut);
     int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
     const double m = 9223372036854775808.0;
@@ -278,9 +297,8 @@ __global__ __launch_bounds__(TB) void k_keys_xyz(const double *__restrict__ xyz,
     X[0] = (uint64_t)(xyz[3 * i + 1] * m);
     X[1] = (uint64_t)(xyz[3 * i + 2] * m);
     X[2] = (uint64_t)(xyz[3 * i + 0] * m);
-    tc_hilbert_transpose(X);
     uint64_t hi, lo;
-    tc_key_from_transpose(X, &hi, &lo);
+    tc_key_lut_from_scaled(X, lut, &hi, &lo);                  /* the product's key path, on the known answers too */
     khi[i] = hi; klo[i] = lo;
 }
 

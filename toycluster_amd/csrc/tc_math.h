@@ -118,6 +118,61 @@ TC_HD void tc_peano_key(float px, float py, float pz, double box, uint64_t *hi, 
     tc_key_from_transpose(X, hi, lo);
 }
 
+/* Table-driven Peano key (tools/gen_hilbert_lut.py): the same 128-bit key as tc_peano_key, two octree levels per
+ * table look-up instead of one bit-serial step per bit.  `lut` = TC_HILBERT_LUT (tc_hilbert_lut.h; the kernels keep
+ * a copy in LDS).  A coordinate equal to the box size (X = 2^63, bit 63 set) takes the bit-serial transform: its
+ * first step is not the start state of the tables. */
+TC_HD void tc_key_lut_from_scaled(uint64_t X[3], const unsigned short *lut, uint64_t *hi, uint64_t *lo)
+{
+    if (((X[0] | X[1] | X[2]) >> 63) != 0) {
+        tc_hilbert_transpose(X);
+        tc_key_from_transpose(X, hi, lo);
+        return;
+    }
+    /* the 42 levels the key holds are bits 62..21: W = X >> 21, pairs of levels from the top */
+    const uint32_t h0 = (uint32_t)(X[0] >> 53), h1 = (uint32_t)(X[1] >> 53), h2 = (uint32_t)(X[2] >> 53);   /* bits 62..53: 5 pairs */
+    const uint32_t l0 = (uint32_t)(X[0] >> 21), l1 = (uint32_t)(X[1] >> 21), l2 = (uint32_t)(X[2] >> 21);   /* bits 52..21: 16 pairs */
+    uint32_t st = 0;                         /* state * 64 */
+    uint64_t oa = 0, ob = 0;                 /* output triplets of levels 1..21 (63 bits) and 22..42 (63 bits) */
+#define TC_HSTEP(c0, c1, c2, sh, dst, pos)                                                                     \
+    {                                                                                                          \
+        const uint32_t d = (((c0) >> (sh)) & 3u) << 4 | (((c1) >> (sh)) & 3u) << 2 | (((c2) >> (sh)) & 3u);    \
+        const uint32_t e = lut[st | d];                                                                        \
+        st = e & 0xffc0u;                                                                                      \
+        dst |= (uint64_t)(e & 63u) << (pos);                                                                   \
+    }
+    /* levels 1..10 */
+    TC_HSTEP(h0, h1, h2, 8, oa, 57) TC_HSTEP(h0, h1, h2, 6, oa, 51) TC_HSTEP(h0, h1, h2, 4, oa, 45)
+    TC_HSTEP(h0, h1, h2, 2, oa, 39) TC_HSTEP(h0, h1, h2, 0, oa, 33)
+    /* levels 11..20 */
+    TC_HSTEP(l0, l1, l2, 30, oa, 27) TC_HSTEP(l0, l1, l2, 28, oa, 21) TC_HSTEP(l0, l1, l2, 26, oa, 15)
+    TC_HSTEP(l0, l1, l2, 24, oa, 9) TC_HSTEP(l0, l1, l2, 22, oa, 3)
+    /* levels 21 | 22: the pair straddles the two halves of the key */
+    {
+        const uint32_t d = ((l0 >> 20) & 3u) << 4 | ((l1 >> 20) & 3u) << 2 | ((l2 >> 20) & 3u);
+        const uint32_t e = lut[st | d];
+        st = e & 0xffc0u;
+        oa |= (uint64_t)((e >> 3) & 7u);
+        ob |= (uint64_t)(e & 7u) << 60;
+    }
+    /* levels 23..42 */
+    TC_HSTEP(l0, l1, l2, 18, ob, 54) TC_HSTEP(l0, l1, l2, 16, ob, 48) TC_HSTEP(l0, l1, l2, 14, ob, 42)
+    TC_HSTEP(l0, l1, l2, 12, ob, 36) TC_HSTEP(l0, l1, l2, 10, ob, 30) TC_HSTEP(l0, l1, l2, 8, ob, 24)
+    TC_HSTEP(l0, l1, l2, 6, ob, 18) TC_HSTEP(l0, l1, l2, 4, ob, 12) TC_HSTEP(l0, l1, l2, 2, ob, 6)
+    TC_HSTEP(l0, l1, l2, 0, ob, 0)
+#undef TC_HSTEP
+    /* key = (oa << 65) | (ob << 2), as tc_key_from_transpose */
+    *hi = (oa << 1) | (ob >> 62);
+    *lo = ob << 2;
+}
+
+TC_HD void tc_peano_key_lut(float px, float py, float pz, double box, const unsigned short *lut, uint64_t *hi, uint64_t *lo)
+{
+    uint64_t X[3];
+    tc_scaled_coords(px, py, pz, box, X);
+    tc_key_lut_from_scaled(X, lut, hi, lo);
+}
+
 /* Number of leading Hilbert levels (triplets, level 1 = bits 62 of X) two keys share.
  * Keys are the 128-bit keys above; level l occupies key bits [128-3l, 128-3l+2]. */
 TC_HD int tc_common_levels(uint64_t ahi, uint64_t alo, uint64_t bhi, uint64_t blo)
