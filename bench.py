@@ -40,6 +40,18 @@ BYTES_ITER_PER_PARTICLE = 868    # whole iteration incl. 128-bit
 PER_GPU_PARTICLES = 2_000_000
 
 
+def workload(n_gas):
+    """BASELINE config 2 shape at n_gas SPH particles: the reference's sample parameter file with Mass_Ratio 0.3125
+    and Ntotal = 2 n_gas, set up and sampled by the C host code exactly as the executable does it (host/tc_setup.c:
+    the reference's positions.c:90-133 with its per-thread erand48 streams; 8 streams on every rank whatever the
+    core count, so every rank draws the same particles).  1.6e7 particles take ~2 s (numpy: a minute)."""
+    from toycluster_amd import hostio
+    par = os.path.join(ROOT, "tests", "golden", "cluster.par")
+    s = hostio.setup_system(par, {"ntotal": 2 * n_gas, "mass_ratio": 0.3125})
+    pos, ids = hostio.sample_gas(s, nthreads=8)
+    return hostio.setup_to_model(s), pos, ids
+
+
 def cpu_baseline(nsample, iters):
     """Time the oracle (CPU restatement, OpenMP) on a bounded sample of the same workload."""
     from toycluster_amd import model as M
@@ -51,8 +63,7 @@ def cpu_baseline(nsample, iters):
             cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
-    m = M.preset("merger", nsample)
-    pos, ids = M.sample_gas(m, nsample, seed=14041981)
+    m, pos, ids = workload(nsample)
     o = O.Oracle(m, pos, ids, nthreads=cores)
     o.find_sph_quantities()                       # warm-up pass: the timed iterations start warm
     t0 = time.time()
@@ -105,8 +116,7 @@ def main():
         uid = shard.bootstrap_unique_id(dist, rank, binding.comm_unique_id)
 
     n_total = args.particles_per_gpu * world
-    m = M.preset("merger", n_total)
-    pos, ids = M.sample_gas(m, n_total, seed=14041981)       # same seed => same particles on every rank
+    m, pos, ids = workload(n_total)                          # deterministic => the same particles on every rank
 
     g = binding.TcGpu(local_rank, rank=rank, nranks=world, unique_id=uid,
                       options={"force_comm": 1} if args.force_comm else None)
@@ -204,7 +214,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic (beta-model positions sampled by the C host code from the reference's cluster.par, "
+                    "Mass_Ratio 0.3125; random-seeded like the reference: erand48, 8 streams)",
             "config": {"workload": "2-cluster merger (Mass_Ratio 0.3125), %d SPH particles per GPU, "
                                    "WVT iterations (sort + density solve + sweep + move)" % args.particles_per_gpu,
                        "particles_total": n_total,
