@@ -126,6 +126,8 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipMalloc(&c->work_ctr, 8 * 16 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->ngb_cnt, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->lvl_range, 8 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_lvl, sizeof(tc_level_desc) * (TC_MAX_LEVEL + 2)) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_bbox, sizeof(int) * 6 * (TC_MAX_LEVEL + 1)) == hipSuccess;
     ok = ok && hipMalloc(&c->d_count, 4 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->imask, (tc_level_offset(TC_LP_MAX + 1) / 32 + 1) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc(&c->isum, ((size_t)1 << (3 * TC_LS)) / 8) == hipSuccess;
@@ -153,7 +155,7 @@ static void free_particles(tcgpu_ctx *c)
         TC_FREE(c->g_vhf[b]); TC_FREE(c->g_rhom[b]);
     }
     TC_FREE(c->g_key); TC_FREE(c->g_key_sorted);
-    TC_FREE(c->lsel); TC_FREE(c->lg); TC_FREE(c->own_list); TC_FREE(c->pos4); TC_FREE(c->hsml); TC_FREE(c->rho);
+    TC_FREE(c->lsel); TC_FREE(c->lg); TC_FREE(c->own_list); TC_FREE(c->pos4); TC_FREE(c->hsml); TC_FREE(c->hsml0); TC_FREE(c->rho);
     TC_FREE(c->vhf); TC_FREE(c->sel_tmp);
     TC_FREE(c->apot); TC_FREE(c->bfld); TC_FREE(c->l_apot);
     TC_FREE(c->key); TC_FREE(c->key_sorted); TC_FREE(c->idx); TC_FREE(c->idx_sorted); TC_FREE(c->sort_tmp);
@@ -172,7 +174,7 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     free_particles(c);
     hipFree(c->d_halo); hipFree(c->red); hipHostFree(c->h_red); hipFree(c->flags); hipHostFree(c->h_flags);
     hipFree(c->orphans); hipFree(c->norph); hipFree(c->work_ctr); hipFree(c->ngb_cnt); hipFree(c->spill);
-    hipFree(c->lvl_range); hipFree(c->d_count); hipFree(c->imask); hipFree(c->isum);
+    hipFree(c->lvl_range); hipFree(c->d_lvl); hipFree(c->d_bbox); hipFree(c->d_count); hipFree(c->imask); hipFree(c->isum);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);
@@ -255,6 +257,7 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         TC_HIP(c, hipMalloc(&c->own_list, cap * sizeof(uint32_t)));
         TC_HIP(c, hipMalloc(&c->pos4, cap * sizeof(float4)));
         TC_HIP(c, hipMalloc(&c->hsml, cap * sizeof(float)));
+        TC_HIP(c, hipMalloc(&c->hsml0, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->rho, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->vhf, cap * sizeof(float)));
         if (tc_select_temp_bytes(cap, &c->sel_tmp_bytes)) TC_FAIL(c, TCGPU_ERR_HIP, "select temp query failed");
@@ -687,6 +690,7 @@ static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
         c->local_full = 1;
         c->nloc = c->n;
         c->lmin_tab = 1;
+        if ((rc = tc_layout_table(c, nullptr))) return rc;
     } else {
         int64_t nloc = 0;
         tc_phase_begin(c, PH_LOCAL);
@@ -1123,7 +1127,12 @@ extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *
     TC_HIP(c, hipStreamSynchronize(c->stream));
     /* the reference uses the tree of the preceding Find_sph_quantities() (src/main.c:54-56); a sharded local set
      * does not survive the presentation, so it is rebuilt here from the converged smoothing lengths */
-    if (!c->index_valid && (rc = build_local(c, !c->g_compact, 1, 0))) return rc;
+    if (!c->index_valid || !c->local_full) {      /* marked from the smoothing lengths alone: the curl's query is that ball */
+        c->mark_ignore_w = 1;
+        rc = build_local(c, !c->g_compact, 1, 0);
+        c->mark_ignore_w = 0;
+        if (rc) return rc;
+    }
     if ((rc = tc_launch_gather_rho_vhf(c))) return rc;
     /* Make_magnetic_field sets Ax = Ay = Az (magnetic_field.c:63-65): then A rides in the w lane of the positions
      * and of the mirror, and the kernel reads no side array per neighbour; any other A takes the general path */
@@ -1150,6 +1159,7 @@ extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *
     }
     TC_HIP(c, hipStreamSynchronize(c->stream));
     tc_phase_collect(c);
+    if (!c->local_full) c->index_valid = 0;       /* that local set was marked for the curl's balls only */
     TC_HIP(c, hipMemcpy(bfld, c->bfld, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     return TCGPU_OK;
 }

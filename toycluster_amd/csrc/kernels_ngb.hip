@@ -192,13 +192,30 @@ struct tc_query {
     bool full[3];         /* the dimension covers the whole ring: no culling there */
     float sf, hpf;        /* cell edge and padded radius (f32 copies for the per-cell culling) */
     float inv_ny, inv_sf;
-    size_t off;           /* table offset of the level */
+    uint32_t off;         /* table offset of the level's box */
+    int ox, oy, oz, ny, nz;   /* ... its origin and the strides of its (x, y, z) layout (tc_level_desc) */
 };
 
 /* table level of a query of radius h (tc_query_level, tc_ctx.h), clamped to the levels this pass built */
 __device__ __forceinline__ int query_level(const tc_dev_const &k, float h)
 {
     return tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmin_tab, k.lmax, h);
+}
+
+/* The constants as ONE particle's queries see them: on a sharded pass every query of the particle is held to the
+ * table levels the marking kernel sized the boxes for (tc_particle_levels; h0 = the carried smoothing length the pass
+ * started from, w = the WVT hsml), on a full set to the whole table. */
+__device__ __forceinline__ tc_dev_const particle_view(const tc_dev_const &k, float h0, float w)
+{
+    tc_dev_const kk = k;
+    if (k.margin_on) {
+        const float rg = tc_margin_radius(h0, w, k.boxsize, k.margin_widen);
+        int la, lb;
+        tc_particle_levels(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmax, h0, rg, &la, &lb);
+        kk.lmin_tab = U(la);
+        kk.lmax = U(lb);
+    }
+    return kk;
 }
 
 __device__ __forceinline__ double query_cell_edge_at(const tc_dev_const &k, int L)
@@ -213,7 +230,11 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
     q.nL = 1 << L;
     const double s = query_cell_edge_at(k, L);
     const double inv_s = (double)q.nL * k.boxinv;
-    q.off = tc_level_offset(L);
+    /* layout of the level's box (wave-uniform: scalar loads) */
+    const tc_level_desc D = k.lvl[L];
+    q.off = U(D.off);
+    q.ox = U(D.ox); q.oy = U(D.oy); q.oz = U(D.oz); q.ny = U(D.ny); q.nz = U(D.nz);
+    const int bo[3] = {q.ox, q.oy, q.oz}, bn[3] = {U(D.nx), q.ny, q.nz};
     /* pad: the f32 predicate can accept pairs a few ulp beyond h, and the per-cell culling below
      * runs in f32 on coordinates of magnitude boxsize (absolute error < 3e-7 boxsize) */
     const double hp = (double)h * (1.0 + 1e-5) + k.boxsize * 2e-6;
@@ -226,13 +247,20 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
         if (!huge) {
             lo = (int)floor(((double)xs[d] - hp) * inv_s);     /* margins in hp absorb the rounding */
             int hi = (int)floor(((double)xs[d] + hp) * inv_s);
+            /* a box narrower than the ring holds every cell a permitted query reaches (marking kernel, same
+             * padding); clamping to it is then a no-op that keeps any other query inside the table */
+            if (bn[d] < q.nL) {
+                if (lo < bo[d]) lo = bo[d];
+                if (hi > bo[d] + bn[d] - 1) hi = bo[d] + bn[d] - 1;
+            }
             nd = hi - lo + 1;
+            if (nd < 0) nd = 0;
         }
         q.full[d] = false;
         if (nd >= q.nL) { nd = q.nL; lo = 0; q.full[d] = true; }
         q.lo[d] = lo; q.nd[d] = nd;
     }
-    q.inv_ny = 1.0f / (float)q.nd[1];
+    q.inv_ny = 1.0f / (float)(q.nd[1] > 0 ? q.nd[1] : 1);
     q.inv_sf = (float)inv_s;
 }
 
@@ -248,7 +276,7 @@ __device__ __forceinline__ void query_row(const tc_query &q, float xi, float yi,
     const int off[2] = {a, b};
     const float xs[2] = {xi, yi};
     float g2 = 0;
-    uint32_t lin = 0;
+    int cxy[2];
     for (int d = 0; d < 2; d++) {
         int u = q.lo[d] + off[d];
         if (!q.full[d]) {
@@ -256,9 +284,10 @@ __device__ __forceinline__ void query_row(const tc_query &q, float xi, float yi,
             float g = xs[d] < clo ? clo - xs[d] : (xs[d] > chi ? xs[d] - chi : 0.0f);
             g2 += g * g;
         }
-        lin = (lin << q.L) | (uint32_t)(u & (q.nL - 1));
+        cxy[d] = u & (q.nL - 1);
     }
-    rowlin = lin << q.L;
+    /* table entry of the row's cell z is rowlin + (z mod 2^L): the box origin is folded in here */
+    rowlin = q.off + (uint32_t)(((cxy[0] - q.ox) * q.ny + (cxy[1] - q.oy)) * q.nz - q.oz);
     c0 = 0;
     len = 0;
     const float rem = q.hpf * q.hpf - g2;
@@ -392,8 +421,8 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
                 const uint32_t rl = __shfl(rowlin, lo_r);
                 const int zc = __shfl(rc0, lo_r) + (int)(m - __shfl(rexcl, lo_r));
                 if (m < (uint32_t)total) {
-                    const uint32_t lin = rl | (uint32_t)((q.lo[2] + zc) & (q.nL - 1));
-                    const uint2 ce = k.cells[q.off + lin];          /* {~first, last+1}, both 0 when empty */
+                    const uint32_t lin = rl + (uint32_t)((q.lo[2] + zc) & (q.nL - 1));
+                    const uint2 ce = k.cells[lin];                  /* {~first, last+1}, both 0 when empty */
                     const uint32_t s0 = ~ce.x, e0 = ce.y;
                     if (e0 > s0) { st = s0; en = e0; }
                 }
@@ -481,7 +510,7 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
     const int lane = lane_id();
     tc_query q;
     query_setup(k, xi, yi, zi, h, q);
-    const uint32_t *cum = k.cum + q.off;
+    const uint32_t *cum = k.cum;                      /* indexed with table entries (rowlin carries the level's offset) */
     const tc_gpos mirror = vgpr_pos(k.mirror);
     const uint32_t padslot = vgpr_u32(k.mirror_pad);
     const int nrow = q.nd[0] * q.nd[1];
@@ -492,7 +521,7 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
         if (rbase + lane < nrow) query_row(q, xi, yi, zi, rbase + lane, rowlin, rc0, rlen);
         uint32_t ra = 0, rb = 0;
         if (rlen > 0) {
-            const uint32_t lin0 = rowlin | (uint32_t)(q.lo[2] + rc0);
+            const uint32_t lin0 = rowlin + (uint32_t)(q.lo[2] + rc0);
             ra = cum[lin0];
             rb = cum[lin0 + (uint32_t)rlen];
         }
@@ -761,11 +790,10 @@ struct tc_dstate {
 };
 
 /* src/sph.c:36-64 from the hsml in `d` on: ball query, raw-count guards, Find_hsml, until done */
-__device__ __forceinline__ void density_loop(const tc_density_args &a, int i, float xi, float yi, float zi,
-                                             const tc_rlist &rl, uint32_t *idx, uint32_t idxcap, const tc_stage &st,
-                                             tc_dstate &d, float rmax)
+__device__ __forceinline__ void density_loop(const tc_density_args &a, const tc_dev_const &k, int i, float xi, float yi,
+                                             float zi, const tc_rlist &rl, uint32_t *idx, uint32_t idxcap,
+                                             const tc_stage &st, tc_dstate &d, float rmax)
 {
-    const tc_dev_const &k = a.k;
     const int lane = lane_id();
     float hsml = d.hsml;
     for (int guard = 0; guard < 4096; guard++) {
@@ -863,7 +891,8 @@ __device__ __forceinline__ void density_one(const tc_density_args &a, int i, con
     tc_dstate d;
     if (!density_init(a, i, d)) return;
     const float rmax = a.k.margin_on ? tc_margin_radius(a.hsml_in[i], pi.w, a.k.boxsize, a.k.margin_widen) : HUGE_VALF;
-    density_loop(a, i, pi.x, pi.y, pi.z, rl, idx, TC_IDXCAP, st, d, rmax);
+    const tc_dev_const k = particle_view(a.k, a.hsml_in[i], pi.w);
+    density_loop(a, k, i, pi.x, pi.y, pi.z, rl, idx, TC_IDXCAP, st, d, rmax);
     density_store(a, i, d);
 }
 
@@ -904,6 +933,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->level_shift = c->level_shift;
     k->level_scale = c->level_scale;
     k->cells = c->cells;
+    k->lvl = c->d_lvl;
     k->orphans = c->orphans;
     k->norph = c->norph;
     k->pos4 = c->pos4;
@@ -971,6 +1001,7 @@ struct tc_wvt_args {
     double step;
     float *delta;       /* 3n xyz interleaved, G order */
     const uint32_t *lg; /* local slot -> G index */
+    const float *hsml0; /* the carried smoothing lengths the pass started from (level ranges of a sharded pass) */
     int *flags;
 };
 
@@ -1082,7 +1113,8 @@ __device__ __forceinline__ void wvt_one(const tc_wvt_args &a, int i, uint32_t *i
 {
     const float4 pi = a.k.pos4[i];
     double d0, d1, d2;
-    wvt_sum(a.k, i, pi, a.step * (double)pi.w, a.flags, idx, TC_IDXCAP, st, d0, d1, d2);
+    const tc_dev_const k = particle_view(a.k, a.hsml0[i], pi.w);
+    wvt_sum(k, i, pi, a.step * (double)pi.w, a.flags, idx, TC_IDXCAP, st, d0, d1, d2);
     if (lane_id() == 0) {
         const size_t g = a.lg[i];
         a.delta[3 * g] = (float)d0;
@@ -1112,6 +1144,7 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
     a.step = step;
     a.delta = c->delta;
     a.lg = c->lg;
+    a.hsml0 = c->hsml0;
     a.flags = c->flags;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
@@ -1165,10 +1198,10 @@ template <bool STATS, bool WVT>
 __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
 {
     const tc_density_args &da = a.d;
-    const tc_dev_const &k = da.k;
     const int lane = lane_id();
     /* the particle's own data is wave-uniform: keep it in scalar registers */
-    const float4 pv = k.pos4[i];
+    const float4 pv = da.k.pos4[i];
+    const tc_dev_const k = particle_view(da.k, da.hsml_in[i], pv.w);
     const float4 pi = make_float4(U(pv.x), U(pv.y), U(pv.z), U(pv.w));
     const float xi = pi.x, yi = pi.y, zi = pi.z;
     constexpr bool do_wvt = WVT;                       /* a.ustep != nullptr */
@@ -1353,7 +1386,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
 
     if (finite && !d.ok && isfinite(d.hsml)) {
         const float rmax = k.margin_on ? tc_margin_radius(da.hsml_in[i], pi.w, k.boxsize, k.margin_widen) : HUGE_VALF;
-        density_loop(da, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d, rmax);
+        density_loop(da, k, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d, rmax);
     }
     if (finite) density_store<STATS>(da, i, d);
 
@@ -1434,9 +1467,9 @@ __device__ __forceinline__ void curl_one_slow(const tc_curl_args &a, int i, uint
 {
     const uint32_t idxcap = TC_IDXCAP;
     const int lane = lane_id();
-    const tc_dev_const &k = a.k;
-    const float4 pi = k.pos4[i];
+    const float4 pi = a.k.pos4[i];
     const float hq = a.hsml[i];
+    const tc_dev_const k = particle_view(a.k, hq, 0.0f);
     const float hq2 = hq * hq;
     const double hsml = hq, rho_i = a.rho[i], vhf = a.vhf[i];
     const double ax = a.apot[3 * (size_t)i], ay = a.apot[3 * (size_t)i + 1], az = a.apot[3 * (size_t)i + 2];
@@ -1507,10 +1540,10 @@ template <bool AW>     /* AW: the three components of A are equal and ride in th
 __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t *idx, uint32_t *ring, const tc_stage &st)
 {
     const int lane = lane_id();
-    const tc_dev_const &k = a.k;
-    const float4 pv = k.pos4[i];
+    const float4 pv = a.k.pos4[i];
     const float xi = U(pv.x), yi = U(pv.y), zi = U(pv.z);
     const float hq = U(a.hsml[i]);
+    const tc_dev_const k = particle_view(a.k, hq, 0.0f);      /* the curl's local set is marked from hsml alone (api.hip) */
     const float hq2 = hq * hq;
     const double hsml = hq, rho_i = a.rho[i], vhf = a.vhf[i];
     const double ax = a.apot[3 * (size_t)i], ay = a.apot[3 * (size_t)i + 1], az = a.apot[3 * (size_t)i + 2];

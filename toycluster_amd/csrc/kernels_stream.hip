@@ -39,9 +39,27 @@ __device__ __forceinline__ size_t tc_sum_bit(size_t x, size_t y, size_t z)      
     return (((x << TC_LS) + y) << TC_LS) + z;
 }
 
+/* Marks are global atomicOr's on a few thousand words that tens of thousands of waves want to set.  A plain
+ * "test first" load does not help: a CU's L1 is never refreshed by other CUs' atomics, so every wave keeps seeing the
+ * stale zero and fires again, and same-address atomics serialise (measured: 1 ms for 2e6 particles).  Each block
+ * therefore walks a CONTIGUOUS chunk of the Peano-ordered own range -- its waves mark nearly the same cells -- and
+ * remembers in LDS which bits of which word it has already set: one 64-bit entry {word index, bits known set}. */
+#define TC_MARK_CACHE 2048
+__device__ __forceinline__ void tc_mark_bit(uint32_t *__restrict__ bits, unsigned long long *cache, uint32_t tag, size_t bit)
+{
+    const uint32_t w = (uint32_t)(bit >> 5) | tag;             /* tag separates pyramid and summary words */
+    const uint32_t m = 1u << (bit & 31);
+    unsigned long long *e = &cache[(w * 2654435761u) >> (32 - 11)];
+    const unsigned long long v = *e;
+    if ((uint32_t)(v >> 32) == w && ((uint32_t)v & m)) return;
+    atomicOr(&bits[bit >> 5], m);
+    *e = (uint32_t)(v >> 32) == w ? (v | m) : (((unsigned long long)w << 32) | m);   /* one 64-bit LDS store: never torn */
+}
+
 /* All 64 lanes mark the cells [c0, c0 + n) (unwrapped coordinates, periodic) of level L -- in the pyramid, or in the
- * coarse summary when imask is the summary and off = 0.  Arguments are wave-uniform. */
-__device__ __forceinline__ void tc_mark_box(uint32_t *__restrict__ bits, int L, size_t off, const int c0[3], const int n[3])
+ * coarse summary when `bits` is the summary and off = 0.  Arguments are wave-uniform. */
+__device__ __forceinline__ void tc_mark_box(uint32_t *__restrict__ bits, unsigned long long *cache, uint32_t tag, int L,
+                                            size_t off, const int c0[3], const int n[3])
 {
     const int nL = 1 << L;
     const int ncell = n[0] * n[1] * n[2];
@@ -49,48 +67,45 @@ __device__ __forceinline__ void tc_mark_box(uint32_t *__restrict__ bits, int L, 
         const int iz = t % n[2], iy = (t / n[2]) % n[1], ix = t / (n[2] * n[1]);
         const size_t x = (size_t)((c0[0] + ix) & (nL - 1)), y = (size_t)((c0[1] + iy) & (nL - 1)),
                      z = (size_t)((c0[2] + iz) & (nL - 1));
-        const size_t bit = off + ((((x << L) + y) << L) + z);
-        const uint32_t m = 1u << (bit & 31);
-        /* test first: thousands of waves mark the same few words, and same-address atomics serialise */
-        if (!(bits[bit >> 5] & m)) atomicOr(&bits[bit >> 5], m);
+        tc_mark_bit(bits, cache, tag, off + ((((x << L) + y) << L) + z));
     }
 }
 
-/* One wavefront per 64 consecutive own particles.
- * Fine levels (where nearly all particles are): the 64 particles are neighbours along the Peano curve and their
- * balls overlap almost completely -- the wave marks the cells of the common bounding box of the 64 balls once,
- * with the largest radius of the wave: about one mark per particle instead of up to 125.
- * Coarse levels (the few particles of the outskirts, whose cells are a sizeable part of the box, so that a
- * bounding box would claim far too much) and waves of mixed levels: ball by ball, the 64 lanes sharing the cells
- * of one ball.  Either way the level-TC_LS summary is marked for the same region. */
+/* One wavefront per 64 consecutive own particles; a block works through a contiguous chunk of the own range.
+ *  - Coarse balls (pyramid level <= TC_LCOARSE: the few particles of the outskirts, whose cells are a sizeable part
+ *    of the box, so that bounding boxes would claim far too much): every lane sets the <= 125 cells of its own ball in
+ *    a block-wide LDS copy of the coarse pyramid levels (ds_or); the block flushes the non-zero words once.
+ *  - Fine balls (where nearly all particles are): the 64 particles are neighbours along the Peano curve and their
+ *    balls overlap almost completely -- the wave marks the cells of the common bounding box of the balls once, with
+ *    the largest radius: about one mark per particle instead of up to 125.  A wave of mixed fine levels or far-flung
+ *    particles goes ball by ball, the 64 lanes sharing the cells of one ball.
+ *  - The level-TC_LS summary (a fast-reject filter: over-inclusion is harmless) gets the bounding box of all the
+ *    wave's balls, in LDS, flushed with the coarse levels.
+ * Per table level the block also accumulates (LDS) the bounding box of the cells its queries can touch and the range
+ * of levels; one set of global atomics per block at the end. */
+#define TC_LCOARSE 5
+#define TC_COARSE_WORDS ((8 + 64 + 512 + 4096 + 32768) / 32 + 1)       /* cells of levels 1..5, tc_level_offset layout */
+#define TC_SUM_WORDS ((1 << (3 * TC_LS)) / 32)
 __global__ __launch_bounds__(TB) void k_mark_interest(const float4 *__restrict__ gpos4, const float *__restrict__ ghsml,
-                                                      int lo, int hi, double box, double box_mant, int box_exp,
+                                                      int lo, int hi, int chunk, double box, double box_mant, int box_exp,
                                                       double level_scale, int level_shift, int lmax, int lp_max, int widen,
-                                                      uint32_t *__restrict__ imask, uint32_t *__restrict__ isum,
-                                                      int *__restrict__ lvl_range)
+                                                      int ignore_w, uint32_t *__restrict__ imask, uint32_t *__restrict__ isum,
+                                                      int *__restrict__ lvl_range, int *__restrict__ bbox)
 {
-    const int g = lo + blockIdx.x * TB + threadIdx.x;
-    const bool act = g < hi;
+    __shared__ unsigned long long cache[TC_MARK_CACHE];
+    __shared__ uint32_t s_coarse[TC_COARSE_WORDS];
+    __shared__ uint32_t s_sum[TC_SUM_WORDS];
+    __shared__ int s_bb[6 * (TC_MAX_LEVEL + 1)];
+    __shared__ int s_lv[2];
+    for (int t = threadIdx.x; t < TC_MARK_CACHE; t += TB) cache[t] = ~0ull;
+    for (int t = threadIdx.x; t < TC_COARSE_WORDS; t += TB) s_coarse[t] = 0;
+    for (int t = threadIdx.x; t < TC_SUM_WORDS; t += TB) s_sum[t] = 0;
+    for (int t = threadIdx.x; t < 6 * (TC_MAX_LEVEL + 1); t += TB) s_bb[t] = (t % 6) < 3 ? (1 << 30) : -1;
+    if (threadIdx.x == 0) { s_lv[0] = TC_MAX_LEVEL + 1; s_lv[1] = 0; }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    float4 p = make_float4(0, 0, 0, 0);
-    float h0 = 0, rg = 0;
-    int la = TC_MAX_LEVEL + 1, lb = 0;
-    if (act) {
-        p = gpos4[g];
-        h0 = ghsml[g];
-        rg = tc_margin_radius(h0, p.w, box, widen);
-        /* table levels the own queries of this pass can ask for: from the margin radius up to the first query */
-        la = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, rg);
-        lb = tc_query_level(box, box_mant, box_exp, level_scale, level_shift, 1, lmax, h0);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        la = min(la, __shfl_xor(la, o));
-        lb = max(lb, __shfl_xor(lb, o));
-    }
-    if (lane == 0 && la <= TC_MAX_LEVEL) {                   /* test first: same-address atomics of 30 000 waves serialise */
-        if (la < lvl_range[0]) atomicMin(&lvl_range[0], la);
-        if (lb > lvl_range[1]) atomicMax(&lvl_range[1], lb);
-    }
+    const int cbeg = lo + blockIdx.x * chunk, cend = min(hi, cbeg + chunk);
+
     /* marking level of a radius: cell edge s with rp/2 <= s < rp, i.e. a ball spans <= 5 cells per dimension
      * (clamped to the pyramid); rp is the radius padded like the cell-table query (query_setup, kernels_ngb.hip) */
     auto level_of = [&](double rp) {
@@ -115,57 +130,138 @@ __global__ __launch_bounds__(TB) void k_mark_interest(const float4 *__restrict__
             if (n[d] >= nL) { n[d] = nL; c0[d] = 0; }
         }
     };
-    const double rp_own = (double)rg * (1.0 + 1e-5) + box * 2e-6;
-    const int L_own = act ? level_of(rp_own) : 0;
-    float rmax = rg;
-    int Lmin = act ? L_own : 99, Lmax = L_own;
-    for (int o = 32; o > 0; o >>= 1) {
-        rmax = fmaxf(rmax, __shfl_xor(rmax, o));
-        Lmin = min(Lmin, __shfl_xor(Lmin, o));
-        Lmax = max(Lmax, __shfl_xor(Lmax, o));
-    }
-    if (Lmax == 0) return;                                   /* a wave without own particles */
-    const int zero3[3] = {0, 0, 0};
-    (void)zero3;
-    if (Lmin >= 5 && Lmax - Lmin <= 1) {
-        const double rp = (double)rmax * (1.0 + 1e-5) + box * 2e-6;
-        const int L = level_of(rp), nL = 1 << L;
-        const double inv_s = (double)nL / box;
-        const float xs[3] = {p.x, p.y, p.z};
-        int w0[3], n[3];
-        bool compact = true;
-        for (int d = 0; d < 3; d++) {
-            int a = act ? (int)floor(((double)xs[d] - rp) * inv_s) : (1 << 30);
-            int b = act ? (int)floor(((double)xs[d] + rp) * inv_s) : -(1 << 30);
-            for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
-            w0[d] = a; n[d] = b - a + 1;
-            if (n[d] > 8) compact = false;                   /* a ball spans <= 5 cells; a compact wave adds one or two */
+
+    for (int base = cbeg + (threadIdx.x & ~63); base < cend; base += TB) {      /* wave-uniform: every wave its 64 particles */
+        const int g = base + lane;
+        const bool act = g < cend;
+        float4 p = make_float4(0, 0, 0, 0);
+        float h0 = 0, rg = 0;
+        int la = TC_MAX_LEVEL + 1, lb = 0;
+        if (act) {
+            p = gpos4[g];
+            h0 = ghsml[g];
+            rg = tc_margin_radius(h0, ignore_w ? 0.0f : p.w, box, widen);
+            /* table levels the own queries of this pass can ask for (tc_particle_levels) */
+            tc_particle_levels(box, box_mant, box_exp, level_scale, level_shift, lmax, h0, rg, &la, &lb);
         }
-        if (compact) {
-            tc_mark_box(imask, L, tc_level_offset(L), w0, n);
-            int s0[3], sn[3];                                /* the same box in summary cells (L >= 5 > TC_LS) */
-            for (int d = 0; d < 3; d++) {
-                const int a = w0[d] >> (L - TC_LS), b = (w0[d] + n[d] - 1) >> (L - TC_LS);
-                s0[d] = a; sn[d] = b - a + 1;
+        const int la_own = la, lb_own = lb;
+        for (int o = 32; o > 0; o >>= 1) {
+            la = min(la, __shfl_xor(la, o));
+            lb = max(lb, __shfl_xor(lb, o));
+        }
+        if (la > TC_MAX_LEVEL) continue;                        /* a wave without own particles */
+        if (lane == 0) { atomicMin(&s_lv[0], la); atomicMax(&s_lv[1], lb); }
+        /* per table level: bounding box of the cells the wave's queries can touch (the query's own padding,
+         * query_setup); a range that leaves [0, 2^L) wraps round the box: the whole ring in that dimension */
+        const double rp_own = (double)rg * (1.0 + 1e-5) + box * 2e-6;
+        {
+            const float xs3[3] = {p.x, p.y, p.z};
+            for (int L = la; L <= lb; L++) {
+                const int nL = 1 << L;
+                const double inv_s = (double)nL / box;
+                const bool in = act && L >= la_own && L <= lb_own;
+                for (int d = 0; d < 3; d++) {
+                    int a = in ? (int)floor(((double)xs3[d] - rp_own) * inv_s) : (1 << 30);
+                    int b = in ? (int)floor(((double)xs3[d] + rp_own) * inv_s) : -(1 << 30);
+                    if (in && (a < 0 || b >= nL)) { a = 0; b = nL - 1; }
+                    for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
+                    if (lane == 0 && a <= b) { atomicMin(&s_bb[6 * L + d], a); atomicMax(&s_bb[6 * L + 3 + d], b); }
+                }
             }
-            tc_mark_box(isum, TC_LS, 0, s0, sn);
-            return;
+        }
+        const int L_own = act ? level_of(rp_own) : 0;
+        /* summary: the bounding box of all the wave's balls at level TC_LS, in LDS */
+        {
+            const int nS = 1 << TC_LS;
+            const double inv_s = (double)nS / box;
+            const float xs3[3] = {p.x, p.y, p.z};
+            int s0[3], sn[3];
+            for (int d = 0; d < 3; d++) {
+                int a = act ? (int)floor(((double)xs3[d] - rp_own) * inv_s) : (1 << 30);
+                int b = act ? (int)floor(((double)xs3[d] + rp_own) * inv_s) : -(1 << 30);
+                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
+                s0[d] = a; sn[d] = b - a + 1;
+                if (sn[d] >= nS) { sn[d] = nS; s0[d] = 0; }
+            }
+            const int nc = sn[0] * sn[1] * sn[2];
+            for (int t = lane; t < nc; t += 64) {
+                const int iz = t % sn[2], iy = (t / sn[2]) % sn[1], ix = t / (sn[2] * sn[1]);
+                const size_t sb = tc_sum_bit((size_t)((s0[0] + ix) & (nS - 1)), (size_t)((s0[1] + iy) & (nS - 1)),
+                                             (size_t)((s0[2] + iz) & (nS - 1)));
+                atomicOr(&s_sum[sb >> 5], 1u << (sb & 31));
+            }
+        }
+        /* coarse balls: lane by lane into the block's LDS copy of the coarse levels */
+        const bool coarse = act && L_own <= TC_LCOARSE;
+        if (coarse) {
+            int c0[3], n[3];
+            ball_cells(p.x, p.y, p.z, rp_own, L_own, c0, n);
+            const int nL = 1 << L_own;
+            const size_t off = tc_level_offset(L_own);
+            for (int ix = 0; ix < n[0]; ix++)
+                for (int iy = 0; iy < n[1]; iy++)
+                    for (int iz = 0; iz < n[2]; iz++) {
+                        const size_t x = (size_t)((c0[0] + ix) & (nL - 1)), y = (size_t)((c0[1] + iy) & (nL - 1)),
+                                     z = (size_t)((c0[2] + iz) & (nL - 1));
+                        const size_t bit = off + ((((x << L_own) + y) << L_own) + z);
+                        atomicOr(&s_coarse[bit >> 5], 1u << (bit & 31));
+                    }
+        }
+        /* fine balls */
+        const bool fine = act && !coarse;
+        float rmax = fine ? rg : 0.0f;
+        int Lmin = fine ? L_own : 99, Lmax = fine ? L_own : 0;
+        for (int o = 32; o > 0; o >>= 1) {
+            rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+            Lmin = min(Lmin, __shfl_xor(Lmin, o));
+            Lmax = max(Lmax, __shfl_xor(Lmax, o));
+        }
+        if (Lmax == 0) continue;                                 /* no fine ball in this wave */
+        bool done = false;
+        if (Lmax - Lmin <= 1) {
+            const double rp = (double)rmax * (1.0 + 1e-5) + box * 2e-6;
+            const int L = level_of(rp), nL = 1 << L;
+            const double inv_s = (double)nL / box;
+            const float xs[3] = {p.x, p.y, p.z};
+            int w0[3], n[3];
+            bool compact = true;
+            for (int d = 0; d < 3; d++) {
+                int a = fine ? (int)floor(((double)xs[d] - rp) * inv_s) : (1 << 30);
+                int b = fine ? (int)floor(((double)xs[d] + rp) * inv_s) : -(1 << 30);
+                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); b = max(b, __shfl_xor(b, o)); }
+                w0[d] = a; n[d] = b - a + 1;
+                if (n[d] > 8) compact = false;               /* a ball spans <= 5 cells; a compact wave adds one or two */
+            }
+            if (compact) {
+                tc_mark_box(imask, cache, 0u, L, tc_level_offset(L), w0, n);
+                done = true;
+            }
+        }
+        if (!done) {                                             /* ball by ball */
+            uint64_t todo = __ballot(fine);
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float qx = __shfl(p.x, l), qy = __shfl(p.y, l), qz = __shfl(p.z, l);
+                const double rp = __shfl(rp_own, l);
+                const int L = __shfl(L_own, l);
+                int c0[3], n[3];
+                ball_cells(qx, qy, qz, rp, L, c0, n);
+                tc_mark_box(imask, cache, 0u, L, tc_level_offset(L), c0, n);
+            }
         }
     }
-    /* ball by ball */
-    uint64_t todo = __ballot(act);
-    while (todo) {
-        const int l = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const float qx = __shfl(p.x, l), qy = __shfl(p.y, l), qz = __shfl(p.z, l);
-        const double rp = __shfl(rp_own, l);
-        const int L = __shfl(L_own, l);
-        int c0[3], n[3];
-        ball_cells(qx, qy, qz, rp, L, c0, n);
-        tc_mark_box(imask, L, tc_level_offset(L), c0, n);
-        ball_cells(qx, qy, qz, rp, TC_LS, c0, n);
-        tc_mark_box(isum, TC_LS, 0, c0, n);
+    __syncthreads();
+    for (int t = threadIdx.x; t < TC_COARSE_WORDS; t += TB)
+        if (s_coarse[t]) atomicOr(&imask[t], s_coarse[t]);
+    for (int t = threadIdx.x; t < TC_SUM_WORDS; t += TB)
+        if (s_sum[t]) atomicOr(&isum[t], s_sum[t]);
+    for (int t = threadIdx.x; t < 6 * (TC_MAX_LEVEL + 1); t += TB) {
+        const int v = s_bb[t];
+        if ((t % 6) < 3) { if (v < (1 << 30)) atomicMin(&bbox[t], v); }
+        else if (v >= 0) atomicMax(&bbox[t], v);
     }
+    if (threadIdx.x == 0 && s_lv[0] <= TC_MAX_LEVEL) { atomicMin(&lvl_range[0], s_lv[0]); atomicMax(&lvl_range[1], s_lv[1]); }
 }
 
 /* is particle p inside the interest mask?  (orphans -- a coordinate == boxsize, see k_cells -- always are: every
@@ -208,6 +304,11 @@ int tc_select_temp_bytes(size_t n, size_t *bytes)
     auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), tc_in_range{nullptr, 0, 0});
     hipError_t e = rocprim::select(nullptr, b, rocprim::counting_iterator<uint32_t>(0), flags, (uint32_t *)nullptr,
                                    (int *)nullptr, n);
+    size_t b2 = 0;
+    if (e == hipSuccess)
+        e = rocprim::select(nullptr, b2, rocprim::counting_iterator<uint32_t>(0), (unsigned char *)nullptr, (uint32_t *)nullptr,
+                            (int *)nullptr, n);
+    if (b2 > b) b = b2;
     *bytes = b;
     return e == hipSuccess ? 0 : -1;
 }
@@ -220,24 +321,43 @@ int tc_launch_mark_interest(tcgpu_ctx *c)
     int e2 = 0;
     const double mant = 2 * frexp(c->par.boxsize, &e2);
     const int init[8] = {TC_MAX_LEVEL + 1, 0, 0, 0, 0, 0, 0, 0};
+    int binit[6 * (TC_MAX_LEVEL + 1)];
+    for (int L = 0; L <= TC_MAX_LEVEL; L++)
+        for (int d = 0; d < 3; d++) { binit[6 * L + d] = 1 << 30; binit[6 * L + 3 + d] = -1; }
+    TC_HIP(c, hipMemcpyAsync(c->d_bbox, binit, sizeof(binit), hipMemcpyHostToDevice, c->stream));
     TC_HIP(c, hipMemsetAsync(c->imask, 0, (nbits / 32 + 1) * sizeof(uint32_t), c->stream));
     TC_HIP(c, hipMemsetAsync(c->isum, 0, ((size_t)1 << (3 * TC_LS)) / 8, c->stream));
     TC_HIP(c, hipMemcpyAsync(c->lvl_range, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    if (hi > lo)
-        k_mark_interest<<<(unsigned)((hi - lo + TB - 1) / TB), TB, 0, c->stream>>>(
-            c->g_pos4[c->gcur], c->g_hsml[c->gcur], (int)lo, (int)hi, c->par.boxsize, mant, e2 - 1, c->level_scale,
-            c->level_shift, c->lmax, c->lp_max, c->margin_widen, c->imask, c->isum, c->lvl_range);
+    if (hi > lo) {
+        /* contiguous chunks of the own range, a multiple of the block size, about 8 blocks per CU */
+        int64_t nblocks = (int64_t)c->num_cu * (getenv("TCGPU_MARK_BPC") ? atoi(getenv("TCGPU_MARK_BPC")) : 8);
+        int64_t chunk = ((hi - lo + nblocks - 1) / nblocks + TB - 1) / TB * TB;
+        nblocks = (hi - lo + chunk - 1) / chunk;
+        k_mark_interest<<<(unsigned)nblocks, TB, 0, c->stream>>>(
+            c->g_pos4[c->gcur], c->g_hsml[c->gcur], (int)lo, (int)hi, (int)chunk, c->par.boxsize, mant, e2 - 1, c->level_scale,
+            c->level_shift, c->lmax, c->lp_max, c->margin_widen, c->mark_ignore_w, c->imask, c->isum, c->lvl_range,
+            c->d_bbox);
+    }
     TC_HIP(c, hipGetLastError());
     return 0;
+}
+
+/* one byte per particle: inside the interest mask?  (a plain streaming kernel: the test inside the library's
+ * partition kernel ran at a third of this rate) */
+__global__ __launch_bounds__(TB) void k_flag_interest(tc_in_mask pred, int n, unsigned char *__restrict__ flag)
+{
+    int g = blockIdx.x * TB + threadIdx.x;
+    if (g < n) flag[g] = pred((uint32_t)g) ? 1 : 0;
 }
 
 /* lsel = ascending global indices of the particles inside the mask; *nloc their number (synchronises) */
 int tc_select_local(tcgpu_ctx *c, int64_t *nloc)
 {
     tc_in_mask pred{c->g_pos4[c->gcur], c->imask, c->isum, c->par.boxsize, c->lp_max};
-    auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), pred);
+    unsigned char *flag = reinterpret_cast<unsigned char *>(c->idx);          /* n bytes of scratch (the sort's index array) */
+    k_flag_interest<<<(unsigned)((c->n + TB - 1) / TB), TB, 0, c->stream>>>(pred, (int)c->n, flag);
     size_t b = c->sel_tmp_bytes;
-    hipError_t e = rocprim::select(c->sel_tmp, b, rocprim::counting_iterator<uint32_t>(0), flags, c->lsel, c->d_count,
+    hipError_t e = rocprim::select(c->sel_tmp, b, rocprim::counting_iterator<uint32_t>(0), flag, c->lsel, c->d_count,
                                    (size_t)c->n, c->stream);
     TC_HIP(c, e);
     int h[3] = {0, 0, 0};
@@ -247,6 +367,38 @@ int tc_select_local(tcgpu_ctx *c, int64_t *nloc)
     TC_HIP(c, hipStreamSynchronize(c->stream));
     *nloc = h[0];
     c->lmin_tab = h[1] < 1 ? 1 : (h[1] > c->lmax ? c->lmax : h[1]);
+    int bb[6 * (TC_MAX_LEVEL + 1)];
+    TC_HIP(c, hipMemcpy(bb, c->d_bbox, sizeof(bb), hipMemcpyDeviceToHost));
+    return tc_layout_table(c, bb);
+}
+
+/* Lay out this pass's cell table: level by level (lmin_tab..lmax), each the dense array of its bounding box
+ * (bb = {min x, y, z, max x, y, z} per level; NULL = the whole level).  Uploads the descriptors. */
+int tc_layout_table(tcgpu_ctx *c, const int *bb)
+{
+    size_t off = 0;
+    memset(c->h_lvl, 0, sizeof(c->h_lvl));
+    for (int L = c->lmin_tab; L <= c->lmax; L++) {
+        tc_level_desc &D = c->h_lvl[L];
+        const int nL = 1 << L;
+        D.ox = D.oy = D.oz = 0;
+        D.nx = D.ny = D.nz = nL;
+        if (bb) {
+            const int *b = bb + 6 * L;
+            if (b[0] > b[3]) { D.nx = D.ny = D.nz = 0; }            /* no own query uses this level */
+            else {
+                D.ox = b[0]; D.oy = b[1]; D.oz = b[2];
+                D.nx = b[3] - b[0] + 1; D.ny = b[4] - b[1] + 1; D.nz = b[5] - b[2] + 1;
+            }
+        }
+        if (off + (size_t)D.nx * D.ny * D.nz >= ((size_t)1 << 32)) TC_FAIL(c, TCGPU_ERR_NOMEM, "cell table exceeds 2^32 cells");
+        D.off = (uint32_t)off;
+        off += (size_t)D.nx * D.ny * D.nz;
+    }
+    c->h_lvl[c->lmax + 1].off = (uint32_t)off;
+    c->ncells_used = off;
+    if (off > c->ncells_alloc) TC_FAIL(c, TCGPU_ERR_NOMEM, "cell table layout larger than its allocation");
+    TC_HIP(c, hipMemcpyAsync(c->d_lvl, c->h_lvl, sizeof(tc_level_desc) * (TC_MAX_LEVEL + 1), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 
@@ -332,7 +484,7 @@ __global__ __launch_bounds__(TB) void k_gather_local(int nloc, const uint32_t *_
                                                      const uint32_t *__restrict__ lsel,
                                                      const float4 *__restrict__ gpos4, const float *__restrict__ ghsml,
                                                      uint32_t *__restrict__ lg, float4 *__restrict__ pos4,
-                                                     float *__restrict__ hsml)
+                                                     float *__restrict__ hsml, float *__restrict__ hsml0)
 {
     int i = blockIdx.x * TB + threadIdx.x;
     if (i >= nloc) return;
@@ -340,7 +492,9 @@ __global__ __launch_bounds__(TB) void k_gather_local(int nloc, const uint32_t *_
     const uint32_t g = lsel ? lsel[s] : s;
     lg[i] = g;
     pos4[i] = gpos4[g];
-    hsml[i] = ghsml[g];
+    const float h = ghsml[g];
+    hsml[i] = h;
+    hsml0[i] = h;                      /* stays as gathered: the pass's level ranges derive from it (particle_view) */
 }
 
 int tc_launch_gather_local(tcgpu_ctx *c)
@@ -348,7 +502,8 @@ int tc_launch_gather_local(tcgpu_ctx *c)
     const int n = (int)c->nloc;
     tc_phase_begin(c, PH_PERMUTE);
     k_gather_local<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(n, c->idx_sorted, c->local_full ? nullptr : c->lsel,
-                                                           c->g_pos4[c->gcur], c->g_hsml[c->gcur], c->lg, c->pos4, c->hsml);
+                                                           c->g_pos4[c->gcur], c->g_hsml[c->gcur], c->lg, c->pos4, c->hsml,
+                                                           c->hsml0);
     hipError_t e = hipSuccess;
     if (c->nranks > 1) {              /* the own particles' slots, ascending (their number is known: the own range) */
         int64_t lo, hi;
@@ -526,8 +681,18 @@ __device__ __forceinline__ int first_diff_level(const uint32_t a[3], const uint3
     return lmax - top;                /* bit lmax-1 <-> level 1 */
 }
 
+/* table slot of the level-L cell (x, y, z), or false if the cell lies outside the level's box (a ghost far from
+ * every own query: nobody will ask for it) */
+__device__ __forceinline__ bool tc_cell_slot(const tc_level_desc &D, uint32_t x, uint32_t y, uint32_t z, size_t *o)
+{
+    const int ix = (int)x - D.ox, iy = (int)y - D.oy, iz = (int)z - D.oz;
+    if (ix < 0 || ix >= D.nx || iy < 0 || iy >= D.ny || iz < 0 || iz >= D.nz) return false;
+    *o = (size_t)D.off + ((size_t)ix * D.ny + iy) * D.nz + iz;
+    return true;
+}
+
 __global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, int n, double box, int lmax, int lmin_tab,
-                                              uint2 *__restrict__ cells,
+                                              const tc_level_desc *__restrict__ lvl, uint2 *__restrict__ cells,
                                               uint32_t *__restrict__ orphans, int *__restrict__ norph,
                                               int *__restrict__ flags)
 {
@@ -550,9 +715,8 @@ __global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, i
     if (dmin < lmin_tab) dmin = lmin_tab;                  /* levels no query of this pass can ask for are not built */
     for (int L = lmax; L >= dmin; L--) {
         int sh = lmax - L;
-        size_t nL = (size_t)1 << L;
-        size_t lin = (((size_t)(ci[0] >> sh) * nL) + (ci[1] >> sh)) * nL + (ci[2] >> sh);
-        size_t o = tc_level_offset(L) + lin;
+        size_t o;
+        if (!tc_cell_slot(lvl[L], ci[0] >> sh, ci[1] >> sh, ci[2] >> sh, &o)) continue;
         if (L >= dprev) atomicMax(&cells[o].x, ~(uint32_t)i);          /* max(~i) = ~min(i): zero-initialised */
         if (L >= dnext) atomicMax(&cells[o].y, (uint32_t)(i + 1));
     }
@@ -561,11 +725,10 @@ __global__ __launch_bounds__(TB) void k_cells(const float4 *__restrict__ pos4, i
 int tc_launch_cells(tcgpu_ctx *c)
 {
     int n = (int)c->nloc;
-    const size_t first = tc_level_offset(c->lmin_tab), ncell = tc_level_offset(c->lmax + 1) - first;
     tc_phase_begin(c, PH_CELLS);
-    TC_HIP(c, hipMemsetAsync(c->cells + first, 0, ncell * sizeof(uint2), c->stream));
+    TC_HIP(c, hipMemsetAsync(c->cells, 0, c->ncells_used * sizeof(uint2), c->stream));
     TC_HIP(c, hipMemsetAsync(c->norph, 0, sizeof(int), c->stream));
-    k_cells<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4, n, c->par.boxsize, c->lmax, c->lmin_tab, c->cells,
+    k_cells<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4, n, c->par.boxsize, c->lmax, c->lmin_tab, c->d_lvl, c->cells,
                                                      c->orphans, c->norph, c->flags);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
@@ -600,8 +763,9 @@ int tc_scan_temp_bytes(size_t ncell, size_t *bytes)
 }
 
 __global__ __launch_bounds__(TB) void k_mirror(const float4 *__restrict__ pos4, int n, double box, int lmax, int lmin_rm, int lmax_rm,
-                                               const uint2 *__restrict__ cells, const uint32_t *__restrict__ cum,
-                                               float4 *__restrict__ mirror, uint32_t *__restrict__ mirror_idx)
+                                               const tc_level_desc *__restrict__ lvl, const uint2 *__restrict__ cells,
+                                               const uint32_t *__restrict__ cum, float4 *__restrict__ mirror,
+                                               uint32_t *__restrict__ mirror_idx)
 {
     int i = blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
@@ -612,8 +776,8 @@ __global__ __launch_bounds__(TB) void k_mirror(const float4 *__restrict__ pos4, 
     if (orphan) return;                                   /* not in the table (see k_cells) */
     for (int L = lmin_rm; L <= lmax_rm; L++) {
         const int sh = lmax - L;
-        const size_t nL = (size_t)1 << L;
-        const size_t o = tc_level_offset(L) + (((size_t)(ci[0] >> sh) * nL) + (ci[1] >> sh)) * nL + (ci[2] >> sh);
+        size_t o;
+        if (!tc_cell_slot(lvl[L], ci[0] >> sh, ci[1] >> sh, ci[2] >> sh, &o)) continue;
         const uint32_t slot = cum[o] + ((uint32_t)i - ~cells[o].x);
         mirror[slot] = p;
         mirror_idx[slot] = (uint32_t)i;
@@ -625,17 +789,18 @@ int tc_launch_mirror(tcgpu_ctx *c)
     c->mirror_valid = 0;
     if (!c->rows || c->lmax_rm <= 0 || !c->index_valid) return 0;
     const int n = (int)c->nloc;
-    /* scan only the mirrored levels; `cum` is addressed with whole-table cell offsets through a pointer
+    /* scan only the mirrored levels (contiguous in the table); `cum` is addressed with table offsets through a pointer
      * shifted back by the offset of the first mirrored level (tc_cum_base) */
-    const size_t first = tc_level_offset(c->lmin_rm);
-    const size_t ncell = tc_level_offset(c->lmax_rm + 1) - first + 1;     /* +1: the end of the last cell */
+    const size_t first = c->h_lvl[c->lmin_rm].off;
+    const tc_level_desc &T = c->h_lvl[c->lmax_rm];
+    const size_t ncell = (size_t)T.off + (size_t)T.nx * T.ny * T.nz - first + 1;     /* +1: the end of the last cell */
     tc_phase_begin(c, PH_MIRROR);
     auto in = rocprim::make_transform_iterator((const uint2 *)c->cells + first, tc_cell_count());
     size_t b = c->scan_tmp_bytes;
     hipError_t e = rocprim::exclusive_scan(c->scan_tmp, b, in, c->cum, 0u, ncell, rocprim::plus<uint32_t>(), c->stream);
     if (e == hipSuccess)
         k_mirror<<<(n + TB - 1) / TB, TB, 0, c->stream>>>(c->pos4, n, c->par.boxsize, c->lmax, c->lmin_rm, c->lmax_rm,
-                                                         c->cells, tc_cum_base(c), c->mirror, c->mirror_idx);
+                                                         c->d_lvl, c->cells, tc_cum_base(c), c->mirror, c->mirror_idx);
     tc_phase_end(c);
     TC_HIP(c, e);
     TC_HIP(c, hipGetLastError());

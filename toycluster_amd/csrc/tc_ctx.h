@@ -25,6 +25,17 @@ enum tc_phase {
     PH_WVT, PH_MOVE, PH_CURL, PH_COMM, PH_MIRROR, PH_LOCAL, PH_PRESENT, PH_COUNT
 };
 
+/* One level of the cell table: the dense (x, y, z) array, z fastest, of the cells [o, o + n) per dimension -- the
+ * whole level on a full local set, on a sharded rank the bounding box of every cell a permitted query of this pass
+ * can touch at that level (marking kernel).  Cell (x, y, z) lives at off + ((x - ox) ny + (y - oy)) nz + (z - oz);
+ * a dimension whose box is the whole ring (n == 2^L) is addressed modulo 2^L (periodic queries). */
+struct tc_level_desc {
+    uint32_t off;                 /* first cell of the level in `cells` (and, minus the first mirrored level's, in `cum`) */
+    int ox, oy, oz;
+    int nx, ny, nz;
+    int pad;
+};
+
 /* Constants every neighbour kernel needs; passed by value. */
 struct tc_dev_const {
     double boxsize, boxhalf, mpart;
@@ -35,7 +46,8 @@ struct tc_dev_const {
     int lmax;                     /* deepest table level in use */
     int level_shift;              /* added to floor(log2(box/h))+1 when choosing the query level */
     double level_scale;           /* h is multiplied by this before the level is chosen (tuning) */
-    const uint2 *cells;           /* {~first, last+1} per cell; level L at offset tc_level_offset(L) */
+    const uint2 *cells;           /* {~first, last+1} per cell; level L laid out as lvl[L] says */
+    const tc_level_desc *lvl;     /* [TC_MAX_LEVEL + 1] */
     const uint32_t *orphans;      /* particles with a coordinate == boxsize (X has bit 63) */
     const int *norph;
     const float4 *pos4;           /* x,y,z,(w = hsml_wvt) in Peano order */
@@ -86,6 +98,21 @@ __device__ __forceinline__ int tc_query_level(double boxsize, double box_mant, i
 }
 #endif
 
+#if defined(__HIPCC__)
+/* Table levels the queries of one particle may use in a sharded pass: from the level of the margin radius (the widest
+ * permitted query) to one below the level of the carried smoothing length (a query shrunk by the NGBMAX guard,
+ * src/sph.c:42-47, may want finer cells; it gets these -- any level is correct).  The marking kernel sizes the
+ * per-level boxes of the cell table from exactly these ranges, and the solver kernels clamp every query of the
+ * particle into them, so no query can index outside a box. */
+__device__ __forceinline__ void tc_particle_levels(double boxsize, double box_mant, int box_exp, double level_scale,
+                                                   int level_shift, int lmax, float h0, float rg, int *la, int *lb)
+{
+    *la = tc_query_level(boxsize, box_mant, box_exp, level_scale, level_shift, 1, lmax, rg);
+    int b = tc_query_level(boxsize, box_mant, box_exp, level_scale, level_shift, 1, lmax, h0) + 1;
+    *lb = b > lmax ? lmax : b;
+}
+#endif
+
 struct tc_event_rec { int phase; hipEvent_t a, b; };
 
 struct tcgpu_ctx {
@@ -125,10 +152,16 @@ struct tcgpu_ctx {
     int64_t nown;
     float4 *pos4;                 /* local sorted positions (w = WVT hsml) */
     float *hsml, *rho, *vhf;      /* local sorted: carried hsml in, results out */
+    float *hsml0;                 /* local sorted: the carried hsml as gathered (kept through the pass) */
+    int mark_ignore_w;            /* the marking of this local set used hsml only (curl) */
     uint32_t *imask;              /* interest pyramid: one bit per cell of levels 1..lp_max (tc_level_offset layout) */
     int lp_max;
     int *lvl_range;               /* device: [0] = min, [1] = max table level the own queries of this pass can use */
     int lmin_tab;                 /* coarsest level built this pass */
+    tc_level_desc h_lvl[TC_MAX_LEVEL + 2];   /* layout of this pass's cell table (host copy) */
+    tc_level_desc *d_lvl;
+    int *d_bbox;                  /* device: per level {min x, y, z, max x, y, z} of the cells the own queries can touch */
+    size_t ncells_used;           /* cells of this pass's table (cleared every pass) */
     void *sel_tmp;
     size_t sel_tmp_bytes;
     int *d_count;                 /* device: selected count */
@@ -222,7 +255,7 @@ struct tcgpu_ctx {
     } while (0)
 
 /* `cum` holds the prefix sum of the mirrored levels only; kernels index it with whole-table cell offsets */
-static inline const uint32_t *tc_cum_base(const tcgpu_ctx *c) { return c->cum - tc_level_offset(c->lmin_rm); }
+static inline const uint32_t *tc_cum_base(const tcgpu_ctx *c) { return c->cum - c->h_lvl[c->lmin_rm].off; }
 
 /* Scalars of one pass: device doubles at tc_pass_scalars(c); api.hip all-reduces them over the ranks.
  *   [0..2]  sum of the density errors as three 40-bit limbs of an exact fixed-point sum (2^-40 units)
@@ -278,6 +311,7 @@ int tc_launch_keys_xyz(tcgpu_ctx *c, int64_t n, const double *d_xyz, uint64_t *d
 int tc_select_temp_bytes(size_t n, size_t *bytes);
 int tc_launch_mark_interest(tcgpu_ctx *c);      /* imask, lvl_range from the own range (g_hsml, g_pos4.w) */
 int tc_select_local(tcgpu_ctx *c, int64_t *nloc);  /* lsel = particles inside the interest mask; synchronises */
+int tc_layout_table(tcgpu_ctx *c, const int *bbox);   /* h_lvl / d_lvl for this pass (NULL: whole levels) */
 int tc_launch_keys_local(tcgpu_ctx *c);         /* key, idx of the local set; g_key of the own range */
 int tc_launch_gather_local(tcgpu_ctx *c);       /* lg, pos4, hsml in sorted local order; own_list */
 int tc_launch_cells(tcgpu_ctx *c);
