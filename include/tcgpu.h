@@ -161,6 +161,7 @@ int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
  *   "level_scale" [2^(1/4)] the radius is multiplied by this before its level is chosen
  *   "lmax" [auto]     deepest cell-table level (set before upload)
  *   "force_comm" [0]  tests: run the RCCL calls with a 1-rank communicator
+ *   "curl_literal" [0] tests: the curl's literal pair-by-pair path (the NGBMAX-overflow fall-back) for every particle
  *   "ablate" [0]      only honoured by the profiling build libtcgpu_ablate.so (results invalid) */
 int tcgpu_set_option(tcgpu_ctx *ctx, const char *name, double value);
 /* Seconds spent on the device in each phase since the last reset (HIP events on the

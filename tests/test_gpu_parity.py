@@ -499,6 +499,33 @@ def test_curl_larger_case_vs_oracle(gpu):
 
 # ------------------------------------------------------------------ error behaviour
 
+def test_curl_literal_path_matches_staged_path():
+    """k_curl sets particles whose ball holds >= NGBMAX neighbours aside for k_curl_slow, the literal pair-by-pair
+    form with the reference's list truncation (tree.c:91-92); converged smoothing lengths never get there, so the
+    option "curl_literal" sends EVERY particle through it: same B as the staged kernel, A in the w lane or not."""
+    n = 40000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=12)
+    g = binding.TcGpu(0)
+    try:
+        g.set_model(m)
+        g.upload(pos, ids)
+        g.Find_sph_quantities()
+        rng = np.random.default_rng(0)
+        a1 = rng.random(n).astype(np.float32)
+        equal = np.repeat(a1[:, None], 3, axis=1)                       # Ax = Ay = Az: rides in the w lane
+        general = rng.random((n, 3)).astype(np.float32)                # the 3-component path
+        for apot in (equal, general):
+            g.set_option("curl_literal", 0)
+            b_fast = g.Bfld_from_rotA_SPH(apot)
+            g.set_option("curl_literal", 1)
+            b_lit = g.Bfld_from_rotA_SPH(apot)
+            scale = np.abs(b_lit).max()
+            assert np.isfinite(b_fast).all() and np.abs(b_fast - b_lit).max() < 1e-5 * scale
+    finally:
+        g.close()
+
+
 def test_out_of_box_coordinate_is_reported(gpu):
     n = 2000
     m = M.preset("single", n)

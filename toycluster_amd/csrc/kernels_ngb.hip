@@ -1702,7 +1702,12 @@ int tc_launch_curl(tcgpu_ctx *c, float *l_bfld, int a_in_w)
     tc_phase_begin(c, PH_CURL);
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     TC_HIP(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(int), c->stream));
-    if (a_in_w) k_curl<true><<<grid_for(c, nloc, k_curl<true>), TBN, 0, c->stream>>>(a);
+    if (c->curl_literal) {                       /* option "curl_literal" (tests): every particle through the literal path */
+        const int cnt = nloc;
+        if (c->nranks > 1) TC_HIP(c, hipMemcpyAsync(a.ovf_list, c->own_list, (size_t)nloc * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        else if (tc_launch_iota(c, a.ovf_list, (size_t)nloc, 0)) return TCGPU_ERR_HIP;
+        TC_HIP(c, hipMemcpyAsync(c->d_count + 3, &cnt, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    } else if (a_in_w) k_curl<true><<<grid_for(c, nloc, k_curl<true>), TBN, 0, c->stream>>>(a);
     else k_curl<false><<<grid_for(c, nloc, k_curl<false>), TBN, 0, c->stream>>>(a);
     k_curl_slow<<<256, TBN, 0, c->stream>>>(a);
     tc_phase_end(c);

@@ -207,6 +207,7 @@ struct tcgpu_ctx {
     double level_scale;
     int lmax_override;
     int ablate;
+    int curl_literal;             /* option (tests): the curl's literal per-pair path for every particle */
 
     /* scratch */
     float *guess;
