@@ -419,7 +419,7 @@ def test_rccl_code_path_single_rank(golden_case):
     assert (np.abs(p["pos"] - c["r_pos"]).max(axis=1) / c["r_hsml"]).max() < TOL_POS
 
 
-@pytest.mark.parametrize("nranks,n", [(2, 20011), (3, 20011), (8, 60013)])
+@pytest.mark.parametrize("nranks,n", [(2, 20011), (3, 20011), (8, 60013), (4, 2_000_003)])
 def test_sharded_path_with_loopback_ranks(nranks, n):
     """The multi-GPU control flow -- Peano-range shards of the global order, per-rank local sets (own range +
     ghost shell from the interest mask) with their own sort / cell table / mirror, all-gathered positions,
@@ -469,10 +469,14 @@ def test_sharded_path_with_loopback_ranks(nranks, n):
             assert np.array_equal(p[k], p1[k]), (r, k)
         # the warm passes ran on a local set, not on everything: own range < local set < all particles
         assert info["nown"] == min((r + 1) * -(-n // nranks), n) - r * -(-n // nranks)
-        assert info["nown"] < info["nloc"] <= n and info["retries"] <= 1
+        assert info["nown"] < info["nloc"] <= n and info["retries"] <= 2
         assert nbytes > 0
     if nranks == 8:
         assert min(o[2]["nloc"] for o in out) < 0.8 * n          # at least the core ranks work on a compact set
+    if n > 1_000_000:
+        # BASELINE config 2 size.  A rank that owns outskirts particles (hsml up to a fifth of the box at this N, margin
+        # 1.9 x that) legitimately needs nearly everything; the others work on a fraction
+        assert min(o[2]["nloc"] for o in out) < 0.6 * n
 
 
 def test_curl_larger_case_vs_oracle(gpu):

@@ -95,7 +95,7 @@ def main():
     steps = b["steps"]
     txt = ["%s dispatches of `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d --no-cpu-baseline --no-relax`"
            % (DOMINANT, steps, b["warmup"]),
-           "(kernel_trace.csv, End-Start, ms). The first %d dispatches are the untimed warm-up steps (1 = cold start)." % b["warmup"]]
+           "(kernel_trace.csv, End-Start, ms). The dispatches before the last %d are untimed: priming (1 = cold start) and %d warm-up steps." % (steps, b["warmup"])]
     txt += ["  dispatch %d: %.3f ms" % (i + 1, x) for i, x in enumerate(d)]
     txt.append("mean of all %d (the --stats AverageNs): %.3f ms" % (len(d), sum(d) / len(d)))
     txt.append("mean of the %d timed dispatches:        %.3f ms" % (steps, sum(d[-steps:]) / steps))
