@@ -1174,6 +1174,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "level_shift")) c->level_shift = (int)value;
     else if (!strcmp(name, "level_scale")) c->level_scale = value > 0 ? value : 1.0;
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
+    else if (!strcmp(name, "blocks_per_cu")) c->blocks_per_cu = (int)value;   /* profiling: cap the persistent grid */
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
     else if (!strcmp(name, "curl_literal")) c->curl_literal = value != 0;
     else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = c->lmax_rm0 = 0; }

@@ -35,6 +35,31 @@
 #define TC_ABLATE(k) 0
 #endif
 
+/* Stage timers (tools/stage_times.py; make stages -> ../lib/libtcgpu_stages.so): every wave of k_iter accumulates the
+ * shader cycles (s_memtime) it spends in each stage of the per-particle body.  The four waves of a SIMD interleave,
+ * so a stage's share of a wave's life is its share of the launch -- issue slots and stalls alike.  Transitions name
+ * both stages so that the accumulator index is a compile-time constant.  Not compiled into the product. */
+#ifdef TC_PROFILE_STAGES
+#define TC_NSTAGE 10
+struct tc_prof { uint64_t last; uint32_t acc[TC_NSTAGE]; };
+#define TC_PROF_PARAM , tc_prof *prof__ = nullptr
+#define TC_PROF_PASS , prof__
+#define TC_STAGE_SWITCH(from, to)                                                          \
+    do {                                                                                   \
+        if (prof__) {                                                                      \
+            const uint64_t now__ = __builtin_amdgcn_s_memtime();                           \
+            prof__->acc[from] += (uint32_t)(now__ - prof__->last);                         \
+            prof__->last = now__;                                                          \
+        }                                                                                  \
+    } while (0)
+#else
+#define TC_PROF_PARAM
+#define TC_PROF_PASS
+#define TC_STAGE_SWITCH(from, to) do { } while (0)
+#endif
+enum { ST_PROLOGUE = 0, ST_PRODUCER, ST_WINDOW, ST_TEST, ST_CONVERT_D, ST_CONVERT_W, ST_SOLVE_PAIRS, ST_SOLVE_UNIFORM,
+       ST_EPILOGUE, ST_QUEUE };
+
 #define WPB TC_WAVES_PER_BLOCK
 #define TBN (WPB * 64)
 
@@ -337,8 +362,10 @@ __device__ __forceinline__ double pair_r_w(float xi, float yi, float zi, float x
         if (dz < -boxhalf) dz += boxsize;
     }
     /* a sum of squares of f32 differences is 0 or >= 1e-90: far above the 2^-767 where the IEEE root starts
-     * to rescale, so the unscaled core returns the same bits (tc_lean.h) */
-    return tc_sqrt_f64_lean(dx * dx + dy * dy + dz * dz);
+     * to rescale, so the unscaled core returns the same bits (tc_lean.h).  Zero (the particle itself) becomes
+     * 1e-150 instead of a select on the result: its only uses are (float)r == 0 and r * dwk with dwk(u = 0) == -0,
+     * which give the same bits as r == 0 (solve_hsml) */
+    return tc_sqrt_f64_lean_pos(max_f64(dx * dx + dy * dy + dz * dz, 1e-300));
 }
 
 /* cell edge the query of radius h will use */
@@ -505,10 +532,11 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
  */
 template <class Body>
 __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi, float yi, float zi, float h,
-                                                uint32_t *heads, Body &&body)
+                                                uint32_t *heads, Body &&body TC_PROF_PARAM)
 {
     const int lane = lane_id();
     tc_query q;
+    TC_STAGE_SWITCH(ST_PROLOGUE, ST_PRODUCER);
     query_setup(k, xi, yi, zi, h, q);
     const uint32_t *cum = k.cum;                      /* indexed with table entries (rowlin carries the level's offset) */
     const tc_gpos mirror = vgpr_pos(k.mirror);
@@ -534,14 +562,16 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
         const uint32_t jump = ra - bprev;                 /* mod 2^32; the running sum telescopes to a_r - excl_r */
         ncand += total;
         if (TC_ABLATE(k) == 1) continue;
+        /* Mirror slots of the 256 flat candidates [base, base + 256): window of run jumps + running sum.  The slots
+         * of window w + 1 are worked out while the gathers of window w are in flight (they only need LDS and DPP),
+         * so a good part of the gather latency each window used to wait out is spent on work that has to be done anyway. */
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < total; base += 256) {
+        auto slots = [&](uint32_t base, uint32_t (&j)[4]) {
             reinterpret_cast<uint4 *>(heads)[lane] = make_uint4(0, 0, 0, 0);
             wave_lds_fence();
             if (excl >= base && excl < base + 256 && excl < total) atomicAdd(&heads[excl - base], jump);
             wave_lds_fence();
-            uint32_t hsum[4], j[4];
-            float4 p[4];
+            uint32_t hsum[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) hsum[u] = heads[64 * u + lane];
             wave_incl_scan4(hsum[0], hsum[1], hsum[2], hsum[3]);
@@ -552,17 +582,31 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
                 const uint32_t m = base + 64 * u + lane;
                 j[u] = m < total ? m + sc : padslot;            /* padding lanes: the slot at infinity */
             }
+            wave_lds_fence();
+        };
+        uint32_t j[4], jn[4];
+        TC_STAGE_SWITCH(ST_PRODUCER, ST_WINDOW);
+        if (total > 0) slots(0, j);
+        TC_STAGE_SWITCH(ST_WINDOW, ST_PRODUCER);
+        for (uint32_t base = 0; base < total; base += 256) {
+            TC_STAGE_SWITCH(ST_PRODUCER, ST_WINDOW);
+            float4 p[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) p[u] = ld4(mirror, j[u]);
+            if (base + 256 < total) slots(base + 256, jn);
+            TC_STAGE_SWITCH(ST_WINDOW, ST_TEST);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (base + 64 * u < total) {
                     if (body(j[u], p[u], true)) return ncand;
                 }
             }
-            wave_lds_fence();
+#pragma unroll
+            for (int u = 0; u < 4; u++) j[u] = jn[u];
+            TC_STAGE_SWITCH(ST_TEST, ST_PRODUCER);
         }
     }
+    TC_STAGE_SWITCH(ST_PRODUCER, ST_EPILOGUE);
     return ncand;
 }
 
@@ -678,7 +722,7 @@ __device__ __attribute__((noinline)) double bisect_hsml(double lower, double upp
 template <class List>
 __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart, double bias_const,
                                            float &hsml_io, float &rho_out, float &drho_io,
-                                           uint32_t &iters, uint32_t &pairs)
+                                           uint32_t &iters, uint32_t &pairs TC_PROF_PARAM)
 {
     double upper = (double)hsml_io * TC_SQRT3;
     double lower = 0;
@@ -735,12 +779,14 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
          * `r > hsml` entries are skipped: == (r2 > hsml^2) up to a zero-weight boundary;
          * a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0 */
         double s0 = 0, s1 = 0, s0B = 0, s1B = 0;
+        TC_STAGE_SWITCH(ST_SOLVE_UNIFORM, ST_SOLVE_PAIRS);
         rl.scan(cnt, hsml, [&](double ra, double rb) {
             ra = min_f64(ra, hsml);
             rb = min_f64(rb, hsml);
             term(ra, s0, s1);
             term(rb, s0B, s1B);
         });
+        TC_STAGE_SWITCH(ST_SOLVE_PAIRS, ST_SOLVE_UNIFORM);
         s0 = wsum(s0 + s0B);
         s1 = wsum(s1 + s1B);
         wkNgb = fpt_h3 * s0;
@@ -963,6 +1009,7 @@ static int grid_for(const tcgpu_ctx *c, int nloc, K kernel)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBN, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     int need = (nloc + WPB - 1) / WPB;
+    if (c->blocks_per_cu > 0 && c->blocks_per_cu < per_cu) per_cu = c->blocks_per_cu;   /* profiling: occupancy sweep */
     int cap = c->num_cu * per_cu;
     if (cap > TC_MAX_PERSISTENT_BLOCKS) cap = TC_MAX_PERSISTENT_BLOCKS;
     int g = need < cap ? need : cap;
@@ -1028,14 +1075,14 @@ __device__ __forceinline__ void wvt_pair(const float4 pi, const float4 pj, doubl
      * branch is uniform over the lanes that got here */
     float r, q;
     double rinv;
-    if (tc_ballot(r2 < 1e-24f && r2 > 0.0f)) {
+    if (tc_ballot(r2 < 1e-24f)) {            /* tiny or zero (coincident particles: the reference divides by zero) */
         r = sqrtf(r2);
         q = r / h;
         rinv = 1.0 / (double)r;
     } else {
-        r = tc_sqrt_f32_lean(r2);
+        r = tc_sqrt_f32_lean_pos(r2);
         q = tc_div_f32_lean(r, h);
-        rinv = tc_rcp_f64_lean((double)r);
+        rinv = tc_rcp_f64_lean_nz((double)r);
     }
     /* src/wvt_relax.c:275-281 with t^8 by squaring and a Horner/FMA polynomial (terms move by a few
      * ulp of f64 before wk is rounded to f32, as in solve_hsml) */
@@ -1176,7 +1223,10 @@ struct tc_iter_args {
 };
 
 /* Sized for 4 waves per SIMD (<= 128 VGPRs, 4 blocks x 38.9 KB LDS per CU): measured 4 % faster than 3 waves
- * with 512/384/512 (tools/try_libs.sh, same box).  Longer lists continue in the per-wave global spill. */
+ * with 512/384/512 (tools/try_libs.sh, same box).  Longer lists continue in the per-wave global spill.
+ * Round 2 tried 5 waves per SIMD (one 640-entry region shared by the two lists growing towards each other = 32 KB per
+ * block, 96 VGPRs): the occupancy sweep (tools/occupancy_sweep.py: 30.8 / 16.7 / 12.6 / 10.8 ms at 1 / 2 / 3 / 4 blocks
+ * per CU) promised -10 %, the build lost 4 % (24 VGPRs spilled to scratch, more scalar spills) -- not taken. */
 #define TC_ICAP 512            /* inner entries in LDS */
 #define TC_OCAP 384            /* outer entries in LDS */
 #define TC_ITER_IDXCAP 256
@@ -1195,8 +1245,9 @@ extern "C" int tcgpu_debug_wave_spans(uint64_t *out, int nwaves)
 /* STATS: keep the per-particle work counters (queries, solver iterations, pair evaluations, candidates) that
  * tcgpu_last_density_stats reports; without them the counters are dead code and cost no scalar registers */
 template <bool STATS, bool WVT>
-__device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill)
+__device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill TC_PROF_PARAM)
 {
+    TC_STAGE_SWITCH(ST_QUEUE, ST_PROLOGUE);
     const tc_density_args &da = a.d;
     const int lane = lane_id();
     /* the particle's own data is wave-uniform: keep it in scalar registers */
@@ -1258,48 +1309,84 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         int cs = 0, co = 0, cw = 0;
         int dcnt = 0, dhead = 0, wcnt = 0, whead = 0;
 
-        /* 64 staged density hits -> f64 separations -> inner / outer list */
-        auto convert_d = [&](auto ftag, int nvalid) {
-            constexpr bool F = decltype(ftag)::value;
-            const bool wr = F ? false : wrap;
-            wave_lds_fence();
-            int sl = (dhead + lane) & (TC_STAGE - 1);
-            const bool valid = lane < nvalid;
-            const float4 pj = F ? ld4(vmirror, valid ? dj[sl] : 0u) : k.pos4[valid ? dj[sl] : (uint32_t)i];
-            const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
-            const bool inn = valid && (r2 < h0sq);
-            const bool outr = valid && !inn;
-            double r = 0;
-            if (valid && TC_ABLATE(k) != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
-            const uint64_t m_in = tc_ballot(inn), m_out = tc_ballot(outr);
-            if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
-                if (inn) L.in.lds[cs + mask_rank(m_in)] = r;
-                if (outr) L.out.lds[co + mask_rank(m_out)] = r;
-            } else {
-                if (inn) { int slot = cs + mask_rank(m_in); if (slot < TC_NGBMAX) L.in.put(slot, r); }
-                if (outr) { int slot = co + mask_rank(m_out); if (slot < TC_NGBMAX) L.out.put(slot, r); }
-            }
-            cs = U(cs + (int)__popcll(m_in));
-            co = U(co + (int)__popcll(m_out));
-            dhead = U((dhead + 64) & (TC_STAGE - 1));
-            wave_lds_fence();
-        };
+        /* The sweep's ball is nearly always the smaller one (hsml_wvt * box = 0.96 ... 1.0 hsml on a relaxing state,
+         * 1.23 hsml for the density ball), so candidates are tested ONCE against the larger of the two squares and
+         * staged in one ring; which lists a staged hit belongs to is decided 64 hits at a time in convert_d, on
+         * full waves, from the f32 r2 staged with it -- the reference's predicates exactly (src/tree.c:67-89). */
+        const float smax = U(hwsq > hbsq && do_wvt ? hwsq : hbsq);
+        bool stopped = false;
+
         /* 64 staged sweep hits -> pair terms */
         auto convert_w = [&](auto ftag, int nvalid) {
             constexpr bool F = decltype(ftag)::value;
             const bool wr = F ? false : wrap;
+            TC_STAGE_SWITCH(ST_CONVERT_D, ST_CONVERT_W);
             wave_lds_fence();
             int sl = (whead + lane) & (TC_STAGE - 1);
             const float4 p = F ? ld4(vmirror, lane < nvalid ? wj[sl] : 0u) : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
             if (lane < nvalid && TC_ABLATE(k) != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wr);
             whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
+            TC_STAGE_SWITCH(ST_CONVERT_W, ST_CONVERT_D);
+        };
+        /* 64 staged hits -> f64 separations -> inner / outer list; sweep hits -> second ring (indices).
+         * Returns true when the density lists come close to NGBMAX (the caller then replays the particle with the
+         * plain code, which is exact whenever it runs). */
+        auto convert_d = [&](auto ftag, int nvalid) -> bool {
+            constexpr bool F = decltype(ftag)::value;
+            const bool wr = F ? false : wrap;
+            TC_STAGE_SWITCH(ST_TEST, ST_CONVERT_D);
+            wave_lds_fence();
+            int sl = (dhead + lane) & (TC_STAGE - 1);
+            const bool valid = lane < nvalid;
+            const uint32_t jj = valid ? dj[sl] : (F ? 0u : (uint32_t)i);
+            const float4 pj = F ? ld4(vmirror, jj) : k.pos4[jj];
+            const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
+            const bool ind = valid && (r2 < hbsq);
+            const bool inn = ind && (r2 < h0sq);
+            const bool outr = ind && !inn;
+            double r = 0;
+            if (TC_ABLATE(k) != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
+            const uint64_t m_in = tc_ballot(inn), m_out = tc_ballot(outr);
+            const int slot_in = cs + mask_rank(m_in), slot_out = co + mask_rank(m_out);
+            if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
+                double *dst = inn ? L.in.lds + slot_in : L.out.lds + slot_out;     /* one store per staged hit */
+                if (ind) *dst = r;
+            } else {
+                if (inn) { if (slot_in < TC_NGBMAX) L.in.put(slot_in, r); }
+                if (outr) { if (slot_out < TC_NGBMAX) L.out.put(slot_out, r); }
+            }
+            cs = U(cs + (int)__popcll(m_in));
+            co = U(co + (int)__popcll(m_out));
+            dhead = U((dhead + 64) & (TC_STAGE - 1));
+            if (do_wvt) {
+                const bool hwv = valid && (r2 < hwsq);
+                uint64_t mw = tc_ballot(hwv);
+                cw = U(cw + (int)__popcll(mw));
+                /* the particle itself (the only hit at distance zero, bar coincident particles) is not a sweep
+                 * neighbour: found once per particle, so the test sits behind a wave-uniform branch */
+                bool use = hwv;
+                if (tc_ballot(hwv && r2 == 0.0f)) {
+                    const bool self = hwv && r2 == 0.0f && (F ? k.mirror_idx[jj] == (uint32_t)i : jj == (uint32_t)i);
+                    use = hwv && !self;
+                    mw = tc_ballot(use);
+                }
+                if (use) {
+                    int sl2 = (whead + wcnt + mask_rank(mw)) & (TC_STAGE - 1);
+                    wj[sl2] = jj;
+                }
+                wcnt = U(wcnt + (int)__popcll(mw));
+                if (wcnt >= 64) { convert_w(ftag, 64); wcnt = U(wcnt - 64); }
+            }
+            wave_lds_fence();
+            TC_STAGE_SWITCH(ST_CONVERT_D, ST_TEST);
+            return cs + co + TC_STAGE >= TC_NGBMAX;
         };
         auto gather = [&](auto ftag, uint32_t j, float4 p, bool act) -> bool {
             constexpr bool F = decltype(ftag)::value;
             const bool wr = F ? false : wrap;
             float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wr);
-            const bool hd = act && (r2 < hbsq);
+            const bool hd = act && (r2 < smax);
             const uint64_t md = tc_ballot(hd);
             if (TC_ABLATE(k) == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
             if (hd) {
@@ -1307,44 +1394,31 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                 dj[sl] = (uint32_t)j; dr2[sl] = r2;
             }
             dcnt = U(dcnt + (int)__popcll(md));
-            if (dcnt >= 64) { convert_d(ftag, 64); dcnt = U(dcnt - 64); }
-            if (do_wvt) {
-                const bool hwv = act && (r2 < hwsq);
-                uint64_t mw = tc_ballot(hwv);
-                cw = U(cw + (int)__popcll(mw));
-                /* the particle itself (the only hit at distance zero, bar coincident particles) is not a sweep
-                 * neighbour: found once per particle, so the test sits behind a wave-uniform branch */
-                uint32_t wslot = (uint32_t)mask_rank(mw);
-                bool use = hwv;
-                if (tc_ballot(hwv && r2 == 0.0f)) {
-                    const bool self = hwv && r2 == 0.0f && (F ? k.mirror_idx[j] == (uint32_t)i : j == (uint32_t)i);
-                    use = hwv && !self;
-                    mw = tc_ballot(use);
-                    wslot = (uint32_t)mask_rank(mw);
-                }
-                if (use) {
-                    int sl = (whead + wcnt + (int)wslot) & (TC_STAGE - 1);
-                    wj[sl] = (uint32_t)j;
-                }
-                wcnt = U(wcnt + (int)__popcll(mw));
-                if (wcnt >= 64) { convert_w(ftag, 64); wcnt = U(wcnt - 64); }
+            if (dcnt >= 64) {
+                dcnt = U(dcnt - 64);
+                if (convert_d(ftag, 64)) { stopped = true; return true; }
             }
-            return cs + co + dcnt >= TC_NGBMAX;
+            return false;
         };
         bool overflow;
         if (fast) {
             const std::true_type F;
-            d.ncand += stream_rows(k, xi, yi, zi, R, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
-            overflow = cs + co + dcnt >= TC_NGBMAX;
+            d.ncand += stream_rows(k, xi, yi, zi, R, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); }
+                                   TC_PROF_PASS);
+            overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
+            TC_STAGE_SWITCH(ST_EPILOGUE, ST_TEST);
             if (!overflow) {
                 if (dcnt > 0) convert_d(F, dcnt);
+                TC_STAGE_SWITCH(ST_TEST, ST_CONVERT_D);
                 if (do_wvt && wcnt > 0) convert_w(F, wcnt);
+                TC_STAGE_SWITCH(ST_CONVERT_D, ST_TEST);
             }
+            TC_STAGE_SWITCH(ST_TEST, ST_EPILOGUE);
         } else {
             const std::false_type F;
             d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap,
                                          [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
-            overflow = cs + co + dcnt >= TC_NGBMAX;
+            overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
             if (!overflow) {
                 if (dcnt > 0) convert_d(F, dcnt);
                 if (do_wvt && wcnt > 0) convert_w(F, wcnt);
@@ -1375,7 +1449,10 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                 }
                 if (cnt_use >= 0) {
                     L.cs = cs;
-                    solved = solve_hsml(L, cnt_use, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair);
+                    TC_STAGE_SWITCH(ST_EPILOGUE, ST_SOLVE_UNIFORM);
+                    solved = solve_hsml(L, cnt_use, k.mpart, da.bias_const, d.hsml, d.rho, d.dRhodHsml, d.nit, d.npair
+                                        TC_PROF_PASS);
+                    TC_STAGE_SWITCH(ST_SOLVE_UNIFORM, ST_EPILOGUE);
                 }
             }
             if (solved) d.ok = true;
@@ -1398,7 +1475,17 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             a.ustep[3 * (size_t)i + 2] = u2;
         }
     }
+    TC_STAGE_SWITCH(ST_EPILOGUE, ST_QUEUE);
 }
+
+#ifdef TC_PROFILE_STAGES
+/* profiling build only: per-stage cycles of every wave of the last k_iter launch */
+__device__ uint32_t g_stage_cycles[TC_NSTAGE * TC_MAX_PERSISTENT_BLOCKS * WPB];
+extern "C" int tcgpu_debug_stage_cycles(uint32_t *out, int nwaves)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage_cycles), sizeof(uint32_t) * TC_NSTAGE * (size_t)nwaves) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <bool STATS, bool WVT>
 __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
@@ -1411,7 +1498,17 @@ __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
 #ifdef TC_PROFILE_ABLATE
     const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-    work_queue(a.d.k, [&](int i) { iter_one<STATS, WVT>(a, i, mine, spill); });
+#ifdef TC_PROFILE_STAGES
+    tc_prof prof, *prof__ = &prof;
+    for (int s = 0; s < TC_NSTAGE; s++) prof.acc[s] = 0;
+    prof.last = __builtin_amdgcn_s_memtime();
+#endif
+    work_queue(a.d.k, [&](int i) { iter_one<STATS, WVT>(a, i, mine, spill TC_PROF_PASS); });
+#ifdef TC_PROFILE_STAGES
+    TC_STAGE_SWITCH(ST_QUEUE, ST_QUEUE);
+    if ((threadIdx.x & 63) == 0 && gw < TC_MAX_PERSISTENT_BLOCKS * WPB)
+        for (int s = 0; s < TC_NSTAGE; s++) g_stage_cycles[TC_NSTAGE * gw + s] = prof.acc[s];
+#endif
 #ifdef TC_PROFILE_ABLATE
     if ((threadIdx.x & 63) == 0 && gw < TC_MAX_PERSISTENT_BLOCKS * WPB) {       /* profiling build: wave life span */
         g_wave_span[2 * gw] = t_begin;

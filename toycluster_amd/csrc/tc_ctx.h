@@ -190,6 +190,7 @@ struct tcgpu_ctx {
     int ustep_valid;              /* ustep belongs to the current local order and positions */
     int fuse;                     /* option: use the fused kernel (default 1) */
     int num_cu;
+    int blocks_per_cu;            /* profiling only: cap on the co-resident blocks per CU of the persistent kernels (0 = all) */
     uint32_t *orphans;
     int *norph;
     int *work_ctr;                /* 8 x 16 ints: per-XCD-group particle counters of the dynamic work queue */

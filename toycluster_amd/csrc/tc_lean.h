@@ -24,6 +24,42 @@ __device__ __forceinline__ double tc_sqrt_f64_lean(double x)
     return x == 0 ? x : g;
 }
 
+/* the same core for x > 0 (no zero select) */
+__device__ __forceinline__ double tc_sqrt_f64_lean_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+__device__ __forceinline__ float tc_sqrt_f32_lean_pos(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float em = __builtin_fmaf(-sm, s, x);
+    const float ep = __builtin_fmaf(-sp, s, x);
+    float r = em <= 0.0f ? sm : s;
+    return ep > 0.0f ? sp : r;
+}
+
+__device__ __forceinline__ double tc_rcp_f64_lean_nz(double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double r = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(r, y, y);
+}
+
 __device__ __forceinline__ float tc_sqrt_f32_lean(float x)
 {
     const float s = __builtin_amdgcn_sqrtf(x);
