@@ -760,13 +760,17 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
          * the scalar factors moved out of the neighbour sum, which moves each f64 total by <= a few ulp (the
          * same size as the summation-order difference already present) and saves 4 of 37 instructions per pair
          * and one wave reduction per solver iteration. */
-        auto term = [&](double r, double &s0, double &s1) {
+        /* the inner constant of the W polynomial parked in a VGPR pair (the compiler re-materialises it with two
+         * moves per entry otherwise) */
+        double c25 = 25.0;
+        asm volatile("; park %0" : "+v"(c25));
+        auto term = [&](auto exact, double r, double &s0, double &s1) {
             const float rf = (float)r;
-            const float u = tc_fdiv_apply(fd, rf);
+            const float u = decltype(exact)::value ? rf / fd.b : tc_fdiv_apply_fast(fd, rf);
             const double ud = (double)u;
             const double t = 1 - ud;
             const double t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
-            const double poly = fma(ud, fma(ud, fma(ud, 32.0, 25.0), 8.0), 1.0);
+            const double poly = fma(ud, fma(ud, fma(ud, 32.0, c25), 8.0), 1.0);
             const double wk = (double)(float)(norm_h3 * t8 * poly);
             const double td = (double)(1 - u);
             const double d2 = td * td, d4 = d2 * d2, d7 = d4 * d2 * td;
@@ -777,15 +781,20 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         };
         /* two independent entries per lane and trip: the f64 chains are latency-bound otherwise.
          * `r > hsml` entries are skipped: == (r2 > hsml^2) up to a zero-weight boundary;
-         * a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0 */
+         * a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0.
+         * The quotient's rare exact-division case (one h per wave) selects the loop, not every entry. */
         double s0 = 0, s1 = 0, s0B = 0, s1B = 0;
         TC_STAGE_SWITCH(ST_SOLVE_UNIFORM, ST_SOLVE_PAIRS);
-        rl.scan(cnt, hsml, [&](double ra, double rb) {
-            ra = min_f64(ra, hsml);
-            rb = min_f64(rb, hsml);
-            term(ra, s0, s1);
-            term(rb, s0B, s1B);
-        });
+        auto sweep_list = [&](auto exact) {
+            rl.scan(cnt, hsml, [&](double ra, double rb) {
+                ra = min_f64(ra, hsml);
+                rb = min_f64(rb, hsml);
+                term(exact, ra, s0, s1);
+                term(exact, rb, s0B, s1B);
+            });
+        };
+        if (fd.exact_div) sweep_list(std::true_type());
+        else sweep_list(std::false_type());
         TC_STAGE_SWITCH(ST_SOLVE_PAIRS, ST_SOLVE_UNIFORM);
         s0 = wsum(s0 + s0B);
         s1 = wsum(s1 + s1B);
@@ -1313,7 +1322,9 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
          * 1.23 hsml for the density ball), so candidates are tested ONCE against the larger of the two squares and
          * staged in one ring; which lists a staged hit belongs to is decided 64 hits at a time in convert_d, on
          * full waves, from the f32 r2 staged with it -- the reference's predicates exactly (src/tree.c:67-89). */
-        const float smax = U(hwsq > hbsq && do_wvt ? hwsq : hbsq);
+        float smax = U(hwsq > hbsq && do_wvt ? hwsq : hbsq);
+        asm volatile("v_mov_b32 %0, %0" : "+v"(smax));          /* parked in a VGPR: the scalar file is full (a spilled
+                                                                 * SGPR costs a v_readlane per candidate batch) */
         bool stopped = false;
 
         /* 64 staged sweep hits -> pair terms */
@@ -1330,44 +1341,45 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             TC_STAGE_SWITCH(ST_CONVERT_W, ST_CONVERT_D);
         };
         /* 64 staged hits -> f64 separations -> inner / outer list; sweep hits -> second ring (indices).
+         * Always a full ring segment: the tail pads it with hits at r2 = infinity (pad_stage), so there is no
+         * per-lane validity here, and the lane masks are ballots of the bare f32 compares (a ballot of a combined
+         * predicate costs a select and a second compare): inner = r2 < h0^2 (h0 < hb), outer = in hb, not in h0.
          * Returns true when the density lists come close to NGBMAX (the caller then replays the particle with the
          * plain code, which is exact whenever it runs). */
-        auto convert_d = [&](auto ftag, int nvalid) -> bool {
+        auto convert_d = [&](auto ftag) -> bool {
             constexpr bool F = decltype(ftag)::value;
             const bool wr = F ? false : wrap;
             TC_STAGE_SWITCH(ST_TEST, ST_CONVERT_D);
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
-            const bool valid = lane < nvalid;
-            const uint32_t jj = valid ? dj[sl] : (F ? 0u : (uint32_t)i);
+            const uint32_t jj = dj[sl];
             const float4 pj = F ? ld4(vmirror, jj) : k.pos4[jj];
             const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
-            const bool ind = valid && (r2 < hbsq);
-            const bool inn = ind && (r2 < h0sq);
-            const bool outr = ind && !inn;
+            const bool b_hb = r2 < hbsq, b_h0 = r2 < h0sq;
             double r = 0;
             if (TC_ABLATE(k) != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
-            const uint64_t m_in = tc_ballot(inn), m_out = tc_ballot(outr);
+            const uint64_t m_hb = tc_ballot(b_hb), m_in = tc_ballot(b_h0);
+            const uint64_t m_out = m_hb ^ m_in;                       /* h0 < hb: the inner hits are among m_hb */
             const int slot_in = cs + mask_rank(m_in), slot_out = co + mask_rank(m_out);
             if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
-                double *dst = inn ? L.in.lds + slot_in : L.out.lds + slot_out;     /* one store per staged hit */
-                if (ind) *dst = r;
+                double *dst = b_h0 ? L.in.lds + slot_in : L.out.lds + slot_out;    /* one store per staged hit */
+                if (b_hb) *dst = r;
             } else {
-                if (inn) { if (slot_in < TC_NGBMAX) L.in.put(slot_in, r); }
-                if (outr) { if (slot_out < TC_NGBMAX) L.out.put(slot_out, r); }
+                if (b_h0) { if (slot_in < TC_NGBMAX) L.in.put(slot_in, r); }
+                else if (b_hb) { if (slot_out < TC_NGBMAX) L.out.put(slot_out, r); }
             }
             cs = U(cs + (int)__popcll(m_in));
             co = U(co + (int)__popcll(m_out));
             dhead = U((dhead + 64) & (TC_STAGE - 1));
             if (do_wvt) {
-                const bool hwv = valid && (r2 < hwsq);
+                const bool hwv = r2 < hwsq;
                 uint64_t mw = tc_ballot(hwv);
                 cw = U(cw + (int)__popcll(mw));
                 /* the particle itself (the only hit at distance zero, bar coincident particles) is not a sweep
                  * neighbour: found once per particle, so the test sits behind a wave-uniform branch */
                 bool use = hwv;
-                if (tc_ballot(hwv && r2 == 0.0f)) {
-                    const bool self = hwv && r2 == 0.0f && (F ? k.mirror_idx[jj] == (uint32_t)i : jj == (uint32_t)i);
+                if (tc_ballot(r2 == 0.0f)) {
+                    const bool self = r2 == 0.0f && (F ? k.mirror_idx[jj] == (uint32_t)i : jj == (uint32_t)i);
                     use = hwv && !self;
                     mw = tc_ballot(use);
                 }
@@ -1381,6 +1393,14 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             wave_lds_fence();
             TC_STAGE_SWITCH(ST_CONVERT_D, ST_TEST);
             return cs + co + TC_STAGE >= TC_NGBMAX;
+        };
+        /* pad the ring segment [dcnt, 64) behind the staged hits with entries no predicate accepts */
+        auto pad_stage = [&](uint32_t padj, int nvalid) {
+            if (lane >= nvalid) {
+                int sl = (dhead + lane) & (TC_STAGE - 1);
+                dj[sl] = padj;
+                dr2[sl] = HUGE_VALF;
+            }
         };
         auto gather = [&](auto ftag, uint32_t j, float4 p, bool act) -> bool {
             constexpr bool F = decltype(ftag)::value;
@@ -1396,7 +1416,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             dcnt = U(dcnt + (int)__popcll(md));
             if (dcnt >= 64) {
                 dcnt = U(dcnt - 64);
-                if (convert_d(ftag, 64)) { stopped = true; return true; }
+                if (convert_d(ftag)) { stopped = true; return true; }
             }
             return false;
         };
@@ -1408,7 +1428,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
             TC_STAGE_SWITCH(ST_EPILOGUE, ST_TEST);
             if (!overflow) {
-                if (dcnt > 0) convert_d(F, dcnt);
+                if (dcnt > 0) { pad_stage(0u, dcnt); convert_d(F); }
                 TC_STAGE_SWITCH(ST_TEST, ST_CONVERT_D);
                 if (do_wvt && wcnt > 0) convert_w(F, wcnt);
                 TC_STAGE_SWITCH(ST_CONVERT_D, ST_TEST);
@@ -1420,7 +1440,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                                          [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
             overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
             if (!overflow) {
-                if (dcnt > 0) convert_d(F, dcnt);
+                if (dcnt > 0) { pad_stage((uint32_t)i, dcnt); convert_d(F); }
                 if (do_wvt && wcnt > 0) convert_w(F, wcnt);
             }
         }

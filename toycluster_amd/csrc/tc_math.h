@@ -243,6 +243,14 @@ TC_HD float tc_fdiv_apply(tc_fdiv d, float a)
     return __builtin_fmaf(rem, d.y, q0);
 }
 
+/* the common case of tc_fdiv_apply, for callers that have branched on exact_div themselves */
+TC_HD float tc_fdiv_apply_fast(tc_fdiv d, float a)
+{
+    float q0 = a * d.y;
+    float rem = __builtin_fmaf(-q0, d.b, a);
+    return __builtin_fmaf(rem, d.y, q0);
+}
+
 /* ------------------------------------------------------------------ density model */
 
 typedef struct {
