@@ -419,12 +419,13 @@ def test_rccl_code_path_single_rank(golden_case):
     assert (np.abs(p["pos"] - c["r_pos"]).max(axis=1) / c["r_hsml"]).max() < TOL_POS
 
 
-@pytest.mark.parametrize("nranks,n", [(2, 20011), (3, 20011), (8, 60013), (4, 2_000_003)])
-def test_sharded_path_with_loopback_ranks(nranks, n):
+@pytest.mark.parametrize("nranks,n,ghosts", [(2, 20011, 2), (3, 20011, 1), (3, 20011, 0), (8, 60013, 2), (4, 2_000_003, 1)])
+def test_sharded_path_with_loopback_ranks(nranks, n, ghosts):
     """The multi-GPU control flow -- Peano-range shards of the global order, per-rank local sets (own range +
-    ghost shell from the interest mask) with their own sort / cell table / mirror, all-gathered positions,
-    exact all-reduced sums -- run by `nranks` host threads on this one GPU through the loopback communicator:
-    every rank must end with the single-rank result, bit for bit, log included."""
+    ghost shell from the interest mask) with their own sort / cell table / mirror, the ghost exchange (pyramids
+    all-gathered, only the particles inside a receiver's pyramid sent: ghosts = 2 always, 1 when it moves fewer bytes
+    than every position to every rank, 0 never), exact all-reduced sums -- run by `nranks` host threads on this one GPU through the loopback
+    communicator: every rank must end with the single-rank result, bit for bit, log included."""
     import threading
     # n is not a multiple of nranks: padded tail shard
     m = M.preset("merger", n)
@@ -437,7 +438,7 @@ def test_sharded_path_with_loopback_ranks(nranks, n):
     p1 = g1.particles()
     g1.close()
 
-    ctxs = [binding.TcGpu(0) for _ in range(nranks)]
+    ctxs = [binding.TcGpu(0, options={"ghost_exchange": ghosts}) for _ in range(nranks)]
     binding.loopback_group(ctxs)
     out = [None] * nranks
 
@@ -448,8 +449,9 @@ def test_sharded_path_with_loopback_ranks(nranks, n):
             g.upload(pos, ids)
             log = g.Regularise_sph_particles(max_iter=4)
             info = g.local_set_info()
+            nb = g.comm_bytes()
             g.Find_sph_quantities()
-            out[r] = (log, g.particles(), info, g.comm_bytes())
+            out[r] = (log, g.particles(), info, nb)
         except Exception as e:                      # pragma: no cover
             out[r] = e
     th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]

@@ -29,6 +29,8 @@ struct rccl_api {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*GroupStart)(void);
     ncclResult_t (*GroupEnd)(void);
     ncclResult_t (*CommDestroy)(ncclComm_t);
@@ -47,6 +49,9 @@ struct tc_loop_comm {
     pthread_barrier_t bar;
     void *bufs[16];
     double red[16][16];
+    const uint32_t *sidx[16];  /* ghost exchange: every rank's send buffers and the offsets of its destination groups */
+    const float4 *spos[16];
+    int soff[16][17];
 };
 
 
@@ -129,12 +134,11 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipMalloc(&c->d_lvl, sizeof(tc_level_desc) * (TC_MAX_LEVEL + 2)) == hipSuccess;
     ok = ok && hipMalloc(&c->d_bbox, sizeof(int) * 6 * (TC_MAX_LEVEL + 1)) == hipSuccess;
     ok = ok && hipMalloc(&c->d_count, 4 * sizeof(int)) == hipSuccess;
-    ok = ok && hipMalloc(&c->imask, (tc_level_offset(TC_LP_MAX + 1) / 32 + 1) * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc(&c->isum, ((size_t)1 << (3 * TC_LS)) / 8) == hipSuccess;
     ok = ok && hipMalloc(&c->spill, sizeof(double) * (size_t)TC_MAX_PERSISTENT_BLOCKS * TC_WAVES_PER_BLOCK
                                         * (2 * TC_NGBMAX)) == hipSuccess;
     c->fuse = 1;
     c->rows = 1;
+    c->ghost_mode = 1;
     c->level_shift = 1;                          /* cells of h/4..h/2: fewest candidates per query (tools/fuse_stats.py) */
     c->level_scale = 1.189207115002721;           /* 2^(1/4): cells of h/3.4..h/1.7, measured best (tools/shift_probe.py) */
     ok = ok && hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess;
@@ -156,7 +160,7 @@ static void free_particles(tcgpu_ctx *c)
     }
     TC_FREE(c->g_key); TC_FREE(c->g_key_sorted);
     TC_FREE(c->lsel); TC_FREE(c->lg); TC_FREE(c->own_list); TC_FREE(c->pos4); TC_FREE(c->hsml); TC_FREE(c->hsml0); TC_FREE(c->rho);
-    TC_FREE(c->vhf); TC_FREE(c->sel_tmp);
+    TC_FREE(c->vhf); TC_FREE(c->sel_tmp); TC_FREE(c->ghost_mask); TC_FREE(c->ghost_blk_cnt); TC_FREE(c->ghost_blk_incl);
     TC_FREE(c->apot); TC_FREE(c->bfld); TC_FREE(c->l_apot);
     TC_FREE(c->key); TC_FREE(c->key_sorted); TC_FREE(c->idx); TC_FREE(c->idx_sorted); TC_FREE(c->sort_tmp);
     TC_FREE(c->cells); TC_FREE(c->guess); TC_FREE(c->hwvt); TC_FREE(c->delta); TC_FREE(c->stats); TC_FREE(c->ngb_buf);
@@ -174,7 +178,8 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     free_particles(c);
     hipFree(c->d_halo); hipFree(c->red); hipHostFree(c->h_red); hipFree(c->flags); hipHostFree(c->h_flags);
     hipFree(c->orphans); hipFree(c->norph); hipFree(c->work_ctr); hipFree(c->ngb_cnt); hipFree(c->spill);
-    hipFree(c->lvl_range); hipFree(c->d_lvl); hipFree(c->d_bbox); hipFree(c->d_count); hipFree(c->imask); hipFree(c->isum);
+    hipFree(c->lvl_range); hipFree(c->d_lvl); hipFree(c->d_bbox); hipFree(c->d_count); hipFree(c->pyr_all); hipFree(c->ghost_cnt_mat); free(c->h_cnt_mat);
+    hipFree(c->send_idx); hipFree(c->send_pos); hipFree(c->ghost_idx); hipFree(c->ghost_pos);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);
@@ -279,6 +284,24 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         TC_HIP(c, hipMemset(c->delta, 0, 3 * cap * sizeof(float)));
         TC_HIP(c, hipMemset(c->rhom_next, 0, cap * sizeof(float)));
         c->cap = need;
+    }
+    if (!c->pyr_all) {
+        /* one pyramid (+ summary) per rank, side by side: a rank marks its own chunk, the ghost exchange all-gathers */
+        c->pyr_imask_words = ((tc_level_offset(TC_LP_MAX + 1) / 32 + 1) + 3) & ~(size_t)3;
+        c->pyr_chunk = c->pyr_imask_words + ((size_t)1 << (3 * TC_LS)) / 32;
+        TC_HIP(c, hipMalloc(&c->pyr_all, (size_t)c->nranks * c->pyr_chunk * sizeof(uint32_t)));
+        c->imask = c->pyr_all + (size_t)c->rank * c->pyr_chunk;
+        c->isum = c->imask + c->pyr_imask_words;
+        TC_HIP(c, hipMalloc(&c->ghost_cnt_mat, (size_t)c->nranks * c->nranks * sizeof(int)));
+        c->h_cnt_mat = (int *)calloc((size_t)c->nranks * c->nranks, sizeof(int));
+        if (!c->h_cnt_mat) return TCGPU_ERR_NOMEM;
+    }
+    if ((c->comm || c->loop) && c->nranks <= TC_GHOST_MAXR && !c->ghost_mask) {
+        const size_t slen = (size_t)(need / c->nranks);
+        c->ghost_nblk = (int)((slen + 255) / 256) + 1;
+        TC_HIP(c, hipMalloc(&c->ghost_mask, (slen + 1) * sizeof(uint32_t)));
+        TC_HIP(c, hipMalloc(&c->ghost_blk_cnt, (size_t)c->nranks * c->ghost_nblk * sizeof(int)));
+        TC_HIP(c, hipMalloc(&c->ghost_blk_incl, (size_t)c->nranks * c->ghost_nblk * sizeof(int)));
     }
     int lmax = c->lmax_override > 0 ? c->lmax_override : pick_lmax(n);
     if (lmax > TC_MAX_LEVEL) lmax = TC_MAX_LEVEL;
@@ -385,6 +408,7 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
     c->order_dirty = 0;
     c->g_compact = 0;
     c->w_valid = 0;
+    c->pos_all_valid = 1;                         /* every rank was given every position */
     c->nloc = 0; c->nown = 0; c->local_full = 0;
     c->need_guess = 1;
     if (hsml) {                                   /* warm start: the guess is only read where hsml == 0 */
@@ -442,11 +466,13 @@ static int load_rccl(void)
     g_rccl.CommInitRank = (ncclResult_t(*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(h, "ncclCommInitRank");
     g_rccl.AllGather = (ncclResult_t(*)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t))dlsym(h, "ncclAllGather");
     g_rccl.AllReduce = (ncclResult_t(*)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.Send = (ncclResult_t(*)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t))dlsym(h, "ncclSend");
+    g_rccl.Recv = (ncclResult_t(*)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t))dlsym(h, "ncclRecv");
     g_rccl.GroupStart = (ncclResult_t(*)(void))dlsym(h, "ncclGroupStart");
     g_rccl.GroupEnd = (ncclResult_t(*)(void))dlsym(h, "ncclGroupEnd");
     g_rccl.CommDestroy = (ncclResult_t(*)(ncclComm_t))dlsym(h, "ncclCommDestroy");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce || !g_rccl.GroupStart
-        || !g_rccl.GroupEnd) {
+        || !g_rccl.GroupEnd || !g_rccl.Send || !g_rccl.Recv) {
         dlclose(h);
         return -1;
     }
@@ -491,9 +517,16 @@ static void loop_wait(tcgpu_ctx *c)
     if (L->exclusive) pthread_mutex_lock(&L->token);
 }
 
+static int allgather_chunks(tcgpu_ctx *c, void *base, size_t bytes);
+
 static int allgather_inplace(tcgpu_ctx *c, void *base, size_t esize)
 {
-    size_t bytes = (size_t)c->shard_len * esize;
+    return allgather_chunks(c, base, (size_t)c->shard_len * esize);
+}
+
+/* in-place all-gather of `bytes` per rank: rank q's chunk lives at base + q * bytes on every rank */
+static int allgather_chunks(tcgpu_ctx *c, void *base, size_t bytes)
+{
     c->comm_bytes += (double)bytes * (c->nranks - 1);                 /* received per rank */
     if (c->loop) {
         tc_loop_comm *L = c->loop;
@@ -547,6 +580,7 @@ static int allreduce_scalars(tcgpu_ctx *c, double *buf, int nsum, int nmax)
 }
 
 static inline bool multi(const tcgpu_ctx *c) { return c->comm || c->loop; }
+static int ensure_pos_all(tcgpu_ctx *c);
 
 tc_loop_guard::tc_loop_guard(tcgpu_ctx *ctx) : c(ctx)
 {
@@ -607,6 +641,7 @@ static int present(tcgpu_ctx *c)
     if (!c->order_dirty) return 0;
     int rc = 0;
     const int b = c->gcur;
+    if ((rc = ensure_pos_all(c))) return rc;      /* the permute moves every particle's position */
     tc_phase_begin(c, PH_PRESENT);
     if (multi(c)) {
         if (c->comm) g_rccl.GroupStart();
@@ -665,15 +700,138 @@ static int ensure_w(tcgpu_ctx *c)
         if (rc) return rc;
     }
     if ((rc = tc_launch_scale_hsml_own(c))) return rc;
-    if (multi(c)) {
-        tc_phase_begin(c, PH_COMM);
-        rc = allgather_inplace(c, c->g_pos4[c->gcur], sizeof(float4));
-        tc_phase_end(c);
-        if (rc) return rc;
-    }
     c->w_valid = 1;
     c->local_w_valid = 0;                         /* the local copy of the w lane (if any) predates it */
     c->mirror_valid = 0;
+    if (multi(c)) c->pos_all_valid = 0;           /* the other ranks' copies of the own w lane are stale */
+    return 0;
+}
+
+/* Sharded contexts: make g_pos4 complete -- every rank's own positions and model hsml, ONE in-place all-gather of
+ * 16 B per particle.  Needed by passes over the whole set (cold start, repeated pass, presentation); the steady
+ * state exchanges ghosts only (exchange_ghosts). */
+static int ensure_pos_all(tcgpu_ctx *c)
+{
+    if (!multi(c) || c->pos_all_valid) return 0;
+    tc_phase_begin(c, PH_COMM);
+    int rc = allgather_inplace(c, c->g_pos4[c->gcur], sizeof(float4));
+    tc_phase_end(c);
+    if (rc) return rc;
+    c->pos_all_valid = 1;
+    return 0;
+}
+
+/* Ghost exchange of one sharded pass (after the marking kernel has written this rank's pyramid):
+ *   1. all-gather the pyramids (2.4 MB per rank);
+ *   2. every rank tests ITS OWN particles against the other ranks' pyramids (the test the receivers used to run
+ *      over all positions) and counts per destination; the count matrix is all-gathered (R x R ints) -- the one
+ *      host synchronisation of the pass;
+ *   3. grouped ncclSend / ncclRecv of (global index, position + model hsml) = 20 B per ghost;
+ *   4. received positions land in g_pos4 at their global index; lsel = ascending union of own range and ghosts.
+ * The local set that results is the one the flag pass over all positions selected (same bits, same test), so
+ * everything downstream -- and the bit-identity with the single-rank run -- is unchanged. */
+static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
+{
+    const int R = c->nranks, me = c->rank;
+    int rc;
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    tc_phase_begin(c, PH_COMM);
+    rc = allgather_chunks(c, c->pyr_all, c->pyr_chunk * sizeof(uint32_t));
+    tc_phase_end(c);
+    if (rc) return rc;
+    tc_phase_begin(c, PH_LOCAL);
+    rc = tc_launch_ghost_count(c);
+    tc_phase_end(c);
+    if (rc) return rc;
+    tc_phase_begin(c, PH_COMM);
+    rc = allgather_chunks(c, c->ghost_cnt_mat, (size_t)R * sizeof(int));
+    if (rc) { tc_phase_end(c); return rc; }
+    TC_HIP(c, hipMemcpyAsync(c->h_cnt_mat, c->ghost_cnt_mat, (size_t)R * R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    tc_phase_end(c);
+    if ((rc = tc_finish_local_layout(c))) return rc;                 /* synchronises: counts and table layout */
+    int soff[TC_GHOST_MAXR + 1], roff[TC_GHOST_MAXR + 1];
+    soff[0] = roff[0] = 0;
+    for (int q = 0; q < R; q++) {
+        soff[q + 1] = soff[q] + c->h_cnt_mat[(size_t)me * R + q];      /* row me: what I send to q (0 for q == me) */
+        roff[q + 1] = roff[q] + c->h_cnt_mat[(size_t)q * R + me];      /* column me: what q sends to me */
+    }
+    const size_t nsend = (size_t)soff[R], nrecv = (size_t)roff[R];
+    {
+        /* Is this cheaper than sending every position to every rank?  Not when nearly everything is somebody's
+         * ghost (few particles per rank: thick shells) -- then the next passes all-gather instead and the question
+         * is asked again later.  Decided from the whole count matrix, so every rank decides the same. */
+        double ghosts = 0;
+        for (int q = 0; q < R * R; q++) ghosts += c->h_cnt_mat[q];
+        const double cost_ghost = ghosts * (sizeof(uint32_t) + sizeof(float4))
+                                  + (double)R * (R - 1) * (double)(c->pyr_chunk * sizeof(uint32_t));
+        const double cost_all = (double)R * (double)(c->n - c->shard_len) * sizeof(float4);
+        if (c->ghost_mode == 1 && cost_ghost > cost_all) c->ghost_pause = 15;
+    }
+    if ((int64_t)nrecv + (hi - lo) > c->cap) TC_FAIL(c, TCGPU_ERR_NOMEM, "local set larger than the particle capacity");
+    if (nsend > c->send_cap) {
+        hipFree(c->send_idx); hipFree(c->send_pos);
+        c->send_idx = nullptr; c->send_pos = nullptr; c->send_cap = 0;
+        const size_t cap = nsend + nsend / 4 + 1024;
+        TC_HIP(c, hipMalloc(&c->send_idx, cap * sizeof(uint32_t)));
+        TC_HIP(c, hipMalloc(&c->send_pos, cap * sizeof(float4)));
+        c->send_cap = cap;
+    }
+    if (nrecv > c->ghost_cap) {
+        hipFree(c->ghost_idx); hipFree(c->ghost_pos);
+        c->ghost_idx = nullptr; c->ghost_pos = nullptr; c->ghost_cap = 0;
+        const size_t cap = nrecv + nrecv / 4 + 1024;
+        TC_HIP(c, hipMalloc(&c->ghost_idx, cap * sizeof(uint32_t)));
+        TC_HIP(c, hipMalloc(&c->ghost_pos, cap * sizeof(float4)));
+        c->ghost_cap = cap;
+    }
+    tc_phase_begin(c, PH_LOCAL);
+    rc = tc_launch_ghost_fill(c);
+    tc_phase_end(c);
+    if (rc) return rc;
+    tc_phase_begin(c, PH_COMM);
+    c->comm_bytes += (double)nrecv * (sizeof(uint32_t) + sizeof(float4));
+    if (c->loop) {
+        tc_loop_comm *L = c->loop;
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        L->sidx[me] = c->send_idx; L->spos[me] = c->send_pos;
+        memcpy(L->soff[me], soff, sizeof(int) * (R + 1));
+        loop_wait(c);
+        for (int q = 0; q < R; q++) {
+            const int cnt = roff[q + 1] - roff[q];
+            if (q == me || cnt == 0) continue;
+            TC_HIP(c, hipMemcpyAsync(c->ghost_idx + roff[q], L->sidx[q] + L->soff[q][me], (size_t)cnt * sizeof(uint32_t),
+                                     hipMemcpyDeviceToDevice, c->stream));
+            TC_HIP(c, hipMemcpyAsync(c->ghost_pos + roff[q], L->spos[q] + L->soff[q][me], (size_t)cnt * sizeof(float4),
+                                     hipMemcpyDeviceToDevice, c->stream));
+        }
+        TC_HIP(c, hipStreamSynchronize(c->stream));
+        loop_wait(c);
+    } else {
+        bool bad = g_rccl.GroupStart() != ncclSuccess;
+        for (int q = 0; q < R; q++) {
+            if (q == me) continue;
+            const size_t ns = (size_t)(soff[q + 1] - soff[q]), nr = (size_t)(roff[q + 1] - roff[q]);
+            if (ns) {
+                bad |= g_rccl.Send(c->send_idx + soff[q], ns * sizeof(uint32_t), ncclInt8, q, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+                bad |= g_rccl.Send(c->send_pos + soff[q], ns * sizeof(float4), ncclInt8, q, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+            }
+            if (nr) {
+                bad |= g_rccl.Recv(c->ghost_idx + roff[q], nr * sizeof(uint32_t), ncclInt8, q, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+                bad |= g_rccl.Recv(c->ghost_pos + roff[q], nr * sizeof(float4), ncclInt8, q, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+            }
+        }
+        bad |= g_rccl.GroupEnd() != ncclSuccess;                       /* the group is closed on every path */
+        if (bad) { tc_phase_end(c); TC_FAIL(c, TCGPU_ERR_COMM, "ghost exchange (ncclSend / ncclRecv) failed"); }
+    }
+    tc_phase_end(c);
+    c->nghost = (int64_t)nrecv;
+    c->nghost_lo = roff[me];
+    tc_phase_begin(c, PH_LOCAL);
+    rc = tc_launch_ghost_scatter(c);
+    tc_phase_end(c);
+    if (rc) return rc;
+    *nloc = (int64_t)nrecv + (hi - lo);
     return 0;
 }
 
@@ -687,12 +845,24 @@ static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
     c->index_valid = 0; c->mirror_valid = 0; c->ustep_valid = 0;
     if (!multi(c)) full = 1;
     if (full) {
+        if ((rc = ensure_pos_all(c))) return rc;
         c->local_full = 1;
         c->nloc = c->n;
         c->lmin_tab = 1;
         if ((rc = tc_layout_table(c, nullptr))) return rc;
-    } else {
+    } else if (c->nranks <= TC_GHOST_MAXR && c->ghost_mode != 0 && c->ghost_pause == 0) {
         int64_t nloc = 0;
+        tc_phase_begin(c, PH_LOCAL);
+        rc = tc_launch_mark_interest(c);
+        tc_phase_end(c);
+        if (!rc) rc = exchange_ghosts(c, &nloc);                      /* synchronises: the launch sizes below need nloc */
+        if (rc) return rc;
+        c->local_full = 0;
+        c->nloc = nloc;
+    } else {                                                          /* every position to every rank, then select */
+        int64_t nloc = 0;
+        if (c->ghost_pause > 0) c->ghost_pause--;
+        if ((rc = ensure_pos_all(c))) return rc;
         tc_phase_begin(c, PH_LOCAL);
         rc = tc_launch_mark_interest(c);
         if (!rc) rc = tc_select_local(c, &nloc);                      /* synchronises: the launch sizes below need nloc */
@@ -973,6 +1143,7 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
         if (!c->index_valid) {                    /* e.g. a presentation dropped a sharded local set: rebuild it */
             if ((rc = build_local(c, !c->g_compact, 1, 0))) return rc;
         } else if (!c->local_w_valid) {           /* the model hsml was computed after the local gather */
+            if ((rc = ensure_pos_all(c))) return rc;     /* ... and after the ghosts' w lane travelled */
             if ((rc = tc_launch_refresh_w(c))) return rc;
             c->local_w_valid = 1;
         }
@@ -981,8 +1152,8 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
     }
     if (move) {
         if ((rc = tc_launch_move(c))) return rc;
-        /* sharded contexts complete the moved positions right away, together with the model hsml of the new
-         * positions (one all-gather of 16 B per particle and iteration) */
+        /* sharded contexts work out the model hsml of the new positions right away (it rides in the w lane of the
+         * positions, which the next pass's ghost exchange -- or a full all-gather -- carries to the other ranks) */
         if (multi(c) && (rc = ensure_w(c))) return rc;
     }
     return 0;
@@ -1179,6 +1350,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "curl_literal")) c->curl_literal = value != 0;
     else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = c->lmax_rm0 = 0; }
     else if (!strcmp(name, "force_comm")) c->force_comm = value != 0;   /* tests: 1-rank RCCL communicator */
+    else if (!strcmp(name, "ghost_exchange")) c->ghost_mode = (int)value; /* 0: position all-gather every pass, 1: whichever is cheaper (default), 2: always ghosts */
     else if (!strcmp(name, "lmax")) {
         if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "lmax must be set before tcgpu_upload_particles");
         c->lmax_override = (int)value;

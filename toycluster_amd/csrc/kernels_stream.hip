@@ -309,6 +309,11 @@ int tc_select_temp_bytes(size_t n, size_t *bytes)
         e = rocprim::select(nullptr, b2, rocprim::counting_iterator<uint32_t>(0), (unsigned char *)nullptr, (uint32_t *)nullptr,
                             (int *)nullptr, n);
     if (b2 > b) b = b2;
+    size_t b3 = 0;                                  /* the ghost exchange's scan over [dest][block] counts */
+    if (e == hipSuccess)
+        e = rocprim::inclusive_scan(nullptr, b3, (int *)nullptr, (int *)nullptr, (size_t)TC_GHOST_MAXR * (n / TB + 2),
+                                    rocprim::plus<int>());
+    if (b3 > b) b = b3;
     *bytes = b;
     return e == hipSuccess ? 0 : -1;
 }
@@ -367,6 +372,177 @@ int tc_select_local(tcgpu_ctx *c, int64_t *nloc)
     TC_HIP(c, hipStreamSynchronize(c->stream));
     *nloc = h[0];
     c->lmin_tab = h[1] < 1 ? 1 : (h[1] > c->lmax ? c->lmax : h[1]);
+    int bb[6 * (TC_MAX_LEVEL + 1)];
+    TC_HIP(c, hipMemcpy(bb, c->d_bbox, sizeof(bb), hipMemcpyDeviceToHost));
+    return tc_layout_table(c, bb);
+}
+
+/* ------------------------------------------------------------------ ghost exchange (sharded contexts) */
+
+/* tc_in_mask for coordinates already scaled (one particle is tested against several pyramids) */
+__device__ __forceinline__ bool tc_in_pyramid(const uint64_t X[3], const uint32_t *__restrict__ imask,
+                                              const uint32_t *__restrict__ isum, int lp_max)
+{
+    {
+        const int sh = 63 - TC_LS;
+        const size_t sb = tc_sum_bit((size_t)(X[2] >> sh), (size_t)(X[0] >> sh), (size_t)(X[1] >> sh));
+        if (!(isum[sb >> 5] & (1u << (sb & 31)))) return false;
+    }
+    for (int L = lp_max; L >= 1; L--) {
+        const int sh = 63 - L;
+        const size_t nL = (size_t)1 << L;
+        const size_t bit = tc_level_offset(L) + (((size_t)(X[2] >> sh) * nL) + (size_t)(X[0] >> sh)) * nL + (size_t)(X[1] >> sh);
+        if (imask[bit >> 5] & (1u << (bit & 31))) return true;
+    }
+    return false;
+}
+
+/* Sender side of the ghost exchange: which other ranks' pyramids is each OWN particle inside?  (The same test, on
+ * the same bits, that the receiver's flag pass ran over all positions before -- so the ghost sets are the same.)
+ * One bit per destination rank in mask[]; per block and destination the number of set bits. */
+__global__ __launch_bounds__(TB) void k_ghost_count(const float4 *__restrict__ gpos4, int lo, int hi,
+                                                    const uint32_t *__restrict__ pyr, size_t chunk, size_t imask_words,
+                                                    int rank, int R, double box, int lp_max, uint32_t *__restrict__ mask,
+                                                    int *__restrict__ blk_cnt, int nblk)
+{
+    __shared__ int s_cnt[TC_GHOST_MAXR];
+    if (threadIdx.x < TC_GHOST_MAXR) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int g = lo + blockIdx.x * TB + threadIdx.x;
+    uint32_t m = 0;
+    if (g < hi) {
+        const float4 p = gpos4[g];
+        uint64_t X[3];
+        tc_scaled_coords(p.x, p.y, p.z, box, X);
+        const bool orphan = ((X[0] | X[1] | X[2]) >> 63) != 0;       /* coordinate == boxsize: everybody tests these */
+        for (int q = 0; q < R; q++) {
+            if (q == rank) continue;
+            const uint32_t *im = pyr + (size_t)q * chunk;
+            if (orphan || tc_in_pyramid(X, im, im + imask_words, lp_max)) m |= 1u << q;
+        }
+        mask[g - lo] = m;
+    }
+    for (int q = 0; q < R; q++) {
+        const uint64_t b = __ballot((m >> q) & 1u);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&s_cnt[q], (int)__popcll(b));
+    }
+    __syncthreads();
+    if (threadIdx.x < R) blk_cnt[(size_t)threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+/* this rank's row of the send-count matrix from the inclusive scan of the [dest][block] counts */
+__global__ void k_ghost_counts_row(const int *__restrict__ incl, int nblk, int R, int *__restrict__ row)
+{
+    const int q = threadIdx.x;
+    if (q < R) row[q] = incl[(size_t)(q + 1) * nblk - 1] - (q > 0 ? incl[(size_t)q * nblk - 1] : 0);
+}
+
+/* write the send buffers: grouped by destination, ascending own index inside a group (block offsets from the scan,
+ * ranks inside a block from ballots) -- deterministic */
+__global__ __launch_bounds__(TB) void k_ghost_fill(const float4 *__restrict__ gpos4, int lo, int hi, int R,
+                                                   const uint32_t *__restrict__ mask, const int *__restrict__ blk_cnt,
+                                                   const int *__restrict__ incl, int nblk, uint32_t *__restrict__ send_idx,
+                                                   float4 *__restrict__ send_pos)
+{
+    __shared__ int s_w[TC_GHOST_MAXR][TB / 64];
+    const int g = lo + blockIdx.x * TB + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t m = g < hi ? mask[g - lo] : 0u;
+    uint32_t any = 0;                                           /* destinations present in this wave */
+    for (int q = 0; q < R; q++) {
+        const uint64_t b = __ballot((m >> q) & 1u);
+        if (lane == 0) s_w[q][wave] = (int)__popcll(b);
+        if (b) any |= 1u << q;
+    }
+    __syncthreads();
+    if (!m) return;
+    const float4 p = gpos4[g];
+    for (int q = 0; q < R; q++) {
+        if (!((any >> q) & 1u)) continue;
+        const uint64_t b = __ballot((m >> q) & 1u);             /* lanes with m == 0 have left: they are not in b anyway */
+        if (!((m >> q) & 1u)) continue;
+        const size_t e = (size_t)q * nblk + blockIdx.x;
+        int off = incl[e] - blk_cnt[e];
+        for (int w = 0; w < wave; w++) off += s_w[q][w];
+        off += (int)__popcll(b & ((1ull << lane) - 1));
+        send_idx[off] = (uint32_t)g;
+        send_pos[off] = p;
+    }
+}
+
+/* received ghosts: positions into g_pos4, and the unsorted local set in ascending global index = ghosts of the
+ * lower ranks (as received: by sender, ascending inside), the own range, ghosts of the higher ranks */
+__global__ __launch_bounds__(TB) void k_ghost_scatter(int nghost, int nghost_lo, int own_lo, int nown,
+                                                      const uint32_t *__restrict__ ghost_idx, const float4 *__restrict__ ghost_pos,
+                                                      float4 *__restrict__ gpos4, uint32_t *__restrict__ lsel)
+{
+    const int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= nghost + nown) return;
+    if (t < nghost_lo) {
+        const uint32_t g = ghost_idx[t];
+        gpos4[g] = ghost_pos[t];
+        lsel[t] = g;
+    } else if (t < nghost_lo + nown) {
+        lsel[t] = (uint32_t)(own_lo + (t - nghost_lo));
+    } else {
+        const uint32_t g = ghost_idx[t - nown];
+        gpos4[g] = ghost_pos[t - nown];
+        lsel[t] = g;
+    }
+}
+
+int tc_launch_ghost_count(tcgpu_ctx *c)
+{
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    const int R = c->nranks, nblk = c->ghost_nblk;
+    if (hi > lo)
+        k_ghost_count<<<(unsigned)((hi - lo + TB - 1) / TB), TB, 0, c->stream>>>(
+            c->g_pos4[c->gcur], (int)lo, (int)hi, c->pyr_all, c->pyr_chunk, c->pyr_imask_words, c->rank, R, c->par.boxsize,
+            c->lp_max, c->ghost_mask, c->ghost_blk_cnt, nblk);
+    const int nb = (int)((hi - lo + TB - 1) / TB);
+    if (nb < nblk)        /* a short last shard: the blocks it does not launch count nothing */
+        for (int q = 0; q < R; q++)
+            TC_HIP(c, hipMemsetAsync(c->ghost_blk_cnt + (size_t)q * nblk + nb, 0, (size_t)(nblk - nb) * sizeof(int), c->stream));
+    size_t b = c->sel_tmp_bytes;
+    TC_HIP(c, rocprim::inclusive_scan(c->sel_tmp, b, c->ghost_blk_cnt, c->ghost_blk_incl, (size_t)R * nblk,
+                                      rocprim::plus<int>(), c->stream));
+    k_ghost_counts_row<<<1, 64, 0, c->stream>>>(c->ghost_blk_incl, nblk, R, c->ghost_cnt_mat + (size_t)c->rank * R);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int tc_launch_ghost_fill(tcgpu_ctx *c)
+{
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    if (hi > lo)
+        k_ghost_fill<<<(unsigned)((hi - lo + TB - 1) / TB), TB, 0, c->stream>>>(
+            c->g_pos4[c->gcur], (int)lo, (int)hi, c->nranks, c->ghost_mask, c->ghost_blk_cnt, c->ghost_blk_incl, c->ghost_nblk,
+            c->send_idx, c->send_pos);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int tc_launch_ghost_scatter(tcgpu_ctx *c)
+{
+    int64_t lo, hi;
+    tc_own_range(c, &lo, &hi);
+    const int64_t tot = c->nghost + (hi - lo);
+    if (tot > 0)
+        k_ghost_scatter<<<(unsigned)((tot + TB - 1) / TB), TB, 0, c->stream>>>(
+            (int)c->nghost, (int)c->nghost_lo, (int)lo, (int)(hi - lo), c->ghost_idx, c->ghost_pos, c->g_pos4[c->gcur], c->lsel);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+/* the marking kernel's level range and bounding boxes -> this pass's table layout (synchronises) */
+int tc_finish_local_layout(tcgpu_ctx *c)
+{
+    int h[2] = {0, 0};
+    TC_HIP(c, hipMemcpyAsync(h, c->lvl_range, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    TC_HIP(c, hipStreamSynchronize(c->stream));
+    c->lmin_tab = h[0] < 1 ? 1 : (h[0] > c->lmax ? c->lmax : h[0]);
     int bb[6 * (TC_MAX_LEVEL + 1)];
     TC_HIP(c, hipMemcpy(bb, c->d_bbox, sizeof(bb), hipMemcpyDeviceToHost));
     return tc_layout_table(c, bb);
@@ -1172,6 +1348,7 @@ int tc_launch_move(tcgpu_ctx *c)
     c->index_valid = 0; c->mirror_valid = 0;
     c->ustep_valid = 0;
     c->w_valid = 0;
+    c->pos_all_valid = 0;                         /* sharded contexts: the other ranks' copies of the own range are stale */
     return 0;
 }
 

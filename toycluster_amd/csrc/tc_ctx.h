@@ -171,6 +171,22 @@ struct tcgpu_ctx {
     int local_w_valid;            /* the w lane of the local positions is the current model hsml */
     int lmax_rm0, lmin_rm0;       /* mirrored level range of a full local set (per pass: clipped to lmin_tab) */
     double comm_bytes;            /* bytes received in collectives since the last reset */
+    /* ghost exchange (sharded contexts, <= TC_GHOST_MAXR ranks): every rank's pyramid side by side, then only the
+     * particles inside a receiver's pyramid travel */
+    uint32_t *pyr_all;            /* nranks x pyr_chunk words: rank q's pyramid (imask | isum) at q * pyr_chunk */
+    size_t pyr_chunk, pyr_imask_words;
+    int pos_all_valid;            /* g_pos4 holds the current position of EVERY particle (else: own range + last ghosts) */
+    uint32_t *ghost_mask;         /* own range: destination ranks of each own particle (bit q) */
+    int *ghost_blk_cnt, *ghost_blk_incl;   /* [dest][block] counts and their inclusive scan */
+    int ghost_nblk;
+    int *ghost_cnt_mat, *h_cnt_mat;        /* nranks x nranks send counts (row = sender), device and host */
+    uint32_t *send_idx, *ghost_idx;        /* what this rank sends (grouped by destination) / receives (by sender) */
+    float4 *send_pos, *ghost_pos;
+    size_t send_cap, ghost_cap;
+    int64_t nghost, nghost_lo;    /* ghosts received this pass; those from lower ranks (they precede the own range in lsel) */
+    int ghost_mode;               /* option "ghost_exchange": 0 = position all-gather every pass, 1 = whichever moves fewer
+                                   * bytes (default), 2 = always the ghost exchange */
+    int ghost_pause;              /* passes left on the all-gather path before the ghost exchange is tried again */
     double h3_unit;               /* fixed-point unit (a power of two) of the exact sum of h^3, from the model (set_model) */
 
     /* sort (local set; also the scratch of a presentation) */
@@ -313,6 +329,11 @@ int tc_launch_keys_xyz(tcgpu_ctx *c, int64_t n, const double *d_xyz, uint64_t *d
 int tc_select_temp_bytes(size_t n, size_t *bytes);
 int tc_launch_mark_interest(tcgpu_ctx *c);      /* imask, lvl_range from the own range (g_hsml, g_pos4.w) */
 int tc_select_local(tcgpu_ctx *c, int64_t *nloc);  /* lsel = particles inside the interest mask; synchronises */
+#define TC_GHOST_MAXR 32
+int tc_launch_ghost_count(tcgpu_ctx *c);        /* ghost_mask, per-destination counts -> ghost_cnt_mat row of this rank */
+int tc_launch_ghost_fill(tcgpu_ctx *c);         /* send_idx / send_pos, grouped by destination, ascending index inside */
+int tc_launch_ghost_scatter(tcgpu_ctx *c);      /* received positions -> g_pos4; lsel = lower ghosts, own range, upper ghosts */
+int tc_finish_local_layout(tcgpu_ctx *c);       /* level range + bounding boxes of the marking -> cell table layout; synchronises */
 int tc_layout_table(tcgpu_ctx *c, const int *bbox);   /* h_lvl / d_lvl for this pass (NULL: whole levels) */
 int tc_launch_keys_local(tcgpu_ctx *c);         /* key, idx of the local set; g_key of the own range */
 int tc_launch_gather_local(tcgpu_ctx *c);       /* lg, pos4, hsml in sorted local order; own_list */
