@@ -1730,14 +1730,21 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
             }
             const double r2 = dx * dx + dy * dy + dz * dz;
             if (!(r2 > hsml * hsml)) {          /* src/sph.c:271-272 (a coincident particle gives 0/0 = NaN there and here) */
-                const double r = tc_sqrt_f64_lean(r2);
+                double r, rinv;
+                if (tc_ballot(r2 == 0)) {       /* wave-uniform: the IEEE sequences only where somebody divides by zero */
+                    r = tc_sqrt_f64_lean(r2);
+                    rinv = tc_rcp_f64_lean(r);
+                } else {
+                    r = tc_sqrt_f64_lean_pos(r2);
+                    rinv = tc_rcp_f64_lean_nz(r);
+                }
                 /* sph_kernel_derivative_WC6 (src/sph.c:434-440): u = r/h in f32, t = (double)(1-u), trailing polynomial in f32 */
                 const float u = tc_fdiv_apply(fd, (float)r);
                 const double t = (double)(1 - u);
                 const double t2 = t * t, t4 = t2 * t2, t7 = t4 * t2 * t;
                 const float polyf = __builtin_fmaf(u, __builtin_fmaf(u, 16.0f, 7.0f), 1.0f);
                 const double dwk = (double)(float)(norm_h4 * t7 * (double)u * (double)polyf);
-                const double weight = wfac * dwk * tc_rcp_f64_lean(r);
+                const double weight = wfac * dwk * rinv;
                 if (AW) {
                     const double wdA = weight * (ax - (double)pj.w);         /* dAx = dAy = dAz */
                     b0 = fma(wdA, dz - dy, b0);
@@ -1763,7 +1770,7 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
         uint64_t m = tc_ballot(hit);
         cnt = U(cnt + (int)__popcll(m));
         bool use = hit;
-        if (tc_ballot(hit && r2 == 0.0f)) {                    /* the particle itself is not a neighbour (src/sph.c:243-244) */
+        if (tc_ballot(r2 == 0.0f)) {                           /* the particle itself is not a neighbour (src/sph.c:243-244) */
             const bool self = hit && r2 == 0.0f && (F ? k.mirror_idx[j] == (uint32_t)i : j == (uint32_t)i);
             use = hit && !self;
             m = tc_ballot(use);
@@ -1803,7 +1810,7 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
 }
 
 template <bool AW>
-__global__ __launch_bounds__(TBN, 4) void k_curl(tc_curl_args a)
+__global__ __launch_bounds__(TBN, 5) void k_curl(tc_curl_args a)
 {
     __shared__ __align__(16) uint32_t lds_idx[WPB * TC_IDXCAP];
     __shared__ __align__(16) float lds_ring[WPB * 4 * TC_STAGE];
