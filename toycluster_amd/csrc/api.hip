@@ -766,7 +766,8 @@ static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
         const double cost_ghost = ghosts * (sizeof(uint32_t) + sizeof(float4))
                                   + (double)R * (R - 1) * (double)(c->pyr_chunk * sizeof(uint32_t));
         const double cost_all = (double)R * (double)(c->n - c->shard_len) * sizeof(float4);
-        if (c->ghost_mode == 1 && cost_ghost > cost_all) c->ghost_pause = 15;
+        if (c->ghost_mode == 1 && c->margin_widen == 0 && cost_ghost > cost_all) c->ghost_pause = 7;   /* (a repeated pass
+                                                                                       * has a wider shell: not typical) */
     }
     if ((int64_t)nrecv + (hi - lo) > c->cap) TC_FAIL(c, TCGPU_ERR_NOMEM, "local set larger than the particle capacity");
     if (nsend > c->send_cap) {
