@@ -109,6 +109,15 @@ __device__ __forceinline__ float4 ld4(tc_gpos p, uint32_t j)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+/* x, y, z only (12 of the 16 bytes of a slot): the candidate test of the fused kernel never looks at w, and the four
+ * gathers in flight then hold 12 instead of 16 VGPRs */
+typedef float tc_f3n __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float4 ld3(tc_gpos p, uint32_t j)
+{
+    const tc_f3n v = *reinterpret_cast<const TC_GLOBAL tc_f3n *>(p + j);
+    return make_float4(v.x, v.y, v.z, 0.0f);
+}
+
 __device__ __forceinline__ uint32_t vgpr_u32(uint32_t v)
 {
     asm volatile("v_mov_b32 %0, %0" : "+v"(v));
@@ -557,7 +566,7 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
  * window is the offset -- about a dozen instructions per 64 candidates, no per-cell table reads, no
  * per-lane loops.  body(slot, p, active) as in stream_candidates, but `slot` indexes the mirror.
  */
-template <class Body>
+template <bool XYZ_ONLY = false, class Body>
 __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi, float yi, float zi, float h,
                                                 uint32_t *heads, Body &&body TC_PROF_PARAM)
 {
@@ -619,7 +628,7 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
             TC_STAGE_SWITCH(ST_PRODUCER, ST_WINDOW);
             float4 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = ld4(mirror, j[u]);
+            for (int u = 0; u < 4; u++) p[u] = XYZ_ONLY ? ld3(mirror, j[u]) : ld4(mirror, j[u]);
             if (base + 256 < total) slots(base + 256, jn);
             TC_STAGE_SWITCH(ST_WINDOW, ST_TEST);
 #pragma unroll
@@ -1449,7 +1458,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         bool overflow;
         if (fast) {
             const std::true_type F;
-            d.ncand += stream_rows(k, xi, yi, zi, R, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); }
+            d.ncand += stream_rows<true>(k, xi, yi, zi, R, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); }
                                    TC_PROF_PASS);
             overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
             TC_STAGE_SWITCH(ST_EPILOGUE, ST_TEST);
