@@ -406,6 +406,9 @@ def test_rccl_code_path_single_rank(golden_case):
     c = golden_case
     g = binding.TcGpu(0, options={"force_comm": 1})
     try:
+        # every RCCL entry point the library binds, incl. the ghost exchange's grouped ncclSend / ncclRecv (to the own
+        # rank here), with the payload checked
+        assert g._L.tcgpu_debug_comm_selftest(g._h) == 0, g.last_error() if hasattr(g, "last_error") else "self-test"
         g.set_model(c["model"])
         g.upload(c["pos"], c["ids"])
         log = g.Regularise_sph_particles(max_iter=3)

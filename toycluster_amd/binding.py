@@ -98,6 +98,9 @@ def lib():
         L.tcgpu_stream.argtypes = [vp]
         L.tcgpu_stream.restype = vp
         L.tcgpu_comm_bytes.argtypes = [vp, i32]
+        if hasattr(L, "tcgpu_debug_comm_selftest"):
+            L.tcgpu_debug_comm_selftest.argtypes = [vp]
+            L.tcgpu_debug_comm_selftest.restype = i32
         L.tcgpu_comm_bytes.restype = dbl
         L.tcgpu_local_set_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int32)]
         _lib = L

@@ -611,6 +611,36 @@ static int check_flags_collective(tcgpu_ctx *c)
     return check_flags(c, c->h_red + 32);
 }
 
+/* testing: every RCCL entry point the sharded path uses, through the context's communicator (tests give it a 1-rank
+ * one, option "force_comm"): all-gather and all-reduce in place, and a grouped ncclSend / ncclRecv pair to the own rank
+ * -- the ghost exchange's call pattern -- with the payload checked.  Not part of the public header. */
+extern "C" int tcgpu_debug_comm_selftest(tcgpu_ctx *c)
+{
+    if (!c || !c->comm) return TCGPU_ERR_ARG;
+    TC_HIP(c, hipSetDevice(c->device));
+    const int n = 4096;
+    uint32_t *d = nullptr;
+    TC_HIP(c, hipMalloc(&d, 2 * n * sizeof(uint32_t)));
+    uint32_t *h = (uint32_t *)malloc(2 * n * sizeof(uint32_t));
+    if (!h) { hipFree(d); return TCGPU_ERR_NOMEM; }
+    for (int i = 0; i < n; i++) { h[i] = 0x9e3779b9u * (uint32_t)(i + 1); h[n + i] = 0; }
+    hipError_t e = hipMemcpy(d, h, 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    bool bad = e != hipSuccess;
+    bad |= g_rccl.GroupStart() != ncclSuccess;
+    bad |= g_rccl.Send(d, n * sizeof(uint32_t), ncclInt8, c->rank, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+    bad |= g_rccl.Recv(d + n, n * sizeof(uint32_t), ncclInt8, c->rank, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+    bad |= g_rccl.GroupEnd() != ncclSuccess;
+    bad |= g_rccl.AllGather((const char *)d + (size_t)c->rank * n * sizeof(uint32_t) / c->nranks, d,
+                            n * sizeof(uint32_t) / c->nranks, ncclInt8, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+    bad |= hipStreamSynchronize(c->stream) != hipSuccess;
+    bad |= hipMemcpy(h, d, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess;
+    for (int i = 0; i < n && !bad; i++) bad = h[n + i] != 0x9e3779b9u * (uint32_t)(i + 1) || h[i] != h[n + i];
+    free(h);
+    hipFree(d);
+    if (bad) TC_FAIL(c, TCGPU_ERR_COMM, "RCCL self-test failed");
+    return TCGPU_OK;
+}
+
 /* testing: tie `nranks` contexts of this process into a loopback communicator (one thread each) */
 extern "C" int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks)
 {
