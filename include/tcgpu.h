@@ -69,6 +69,11 @@ typedef struct {
     double rcut;         /* Halo[i].Rcut */
     int32_t have_cuspy;  /* Halo[i].Have_Cuspy */
     int32_t reserved;
+    /* The reference's -DDOUBLE_BETA_COOL_CORES build (src/setup.c:604-612) adds a second, narrower beta = 2/3 component
+     * to the profile of halos with Have_Cuspy: rho0_cc = Rho0 * Param.Rho0_Fac, rc_cc = Rcore / Param.Rc_Fac.
+     * rho0_cc == 0 (every halo of the reference's default build) switches the term off. */
+    double rho0_cc;
+    double rc_cc;
 } tcgpu_halo;
 
 /* One line of the reference's convergence log (src/wvt_relax.c:91-92). */

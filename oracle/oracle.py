@@ -95,6 +95,15 @@ def reversed_peano_key(x, y, z):
     return (hi.value << 64) | lo.value
 
 
+def set_double_beta(rho0_fac=0.0, rc_fac=0.0):
+    """The reference's -DDOUBLE_BETA_COOL_CORES build as a process-wide switch of the oracle (Param.Rho0_Fac,
+    Param.Rc_Fac; both 0 = the default build).  Reset it after use."""
+    L = lib()
+    L.orc_set_double_beta.argtypes = [C.c_double, C.c_double]
+    L.orc_set_double_beta.restype = None
+    L.orc_set_double_beta(float(rho0_fac), float(rc_fac))
+
+
 class Oracle:
     """State handle mirroring the reference's globals P / SphP / Param / Halo for the gas particles."""
 

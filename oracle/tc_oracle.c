@@ -655,11 +655,29 @@ void orc_last_stats(const orc_state *s, double *q, double *it, double *p)
 
 /* ---------------------------------------------------------------- density model */
 
-/* setup.c:598-615 without DOUBLE_BETA_COOL_CORES (Makefile default) */
-static inline double gas_density_profile(double r, double rho0, double beta, double rc, double rcut)
+/* Param.Rho0_Fac / Param.Rc_Fac (globals.h:117-120); `double_beta` stands for -DDOUBLE_BETA_COOL_CORES */
+static double Param_Rho0_Fac = 0, Param_Rc_Fac = 0;
+static int double_beta = 0;
+
+void orc_set_double_beta(double rho0_fac, double rc_fac)
 {
-    return rho0 * pow(1 + (r / rc) * (r / rc), -3.0 / 2.0 * beta)
-           / (1 + ((r / rcut) * (r / rcut) * (r / rcut)) * (r / rcut));
+    Param_Rho0_Fac = rho0_fac;
+    Param_Rc_Fac = rc_fac;
+    double_beta = rho0_fac != 0 && rc_fac != 0;
+}
+
+/* setup.c:598-615 */
+static inline double gas_density_profile_c(double r, double rho0, double beta, double rc, double rcut, int Is_Cuspy)
+{
+    double rho = rho0 * pow(1 + (r / rc) * (r / rc), -3.0 / 2.0 * beta)
+                 / (1 + ((r / rcut) * (r / rcut) * (r / rcut)) * (r / rcut));
+    if (double_beta) {                                   /* #ifdef DOUBLE_BETA_COOL_CORES, setup.c:604-612 */
+        double rho0_cc = rho0 * Param_Rho0_Fac;
+        double rc_cc = rc / Param_Rc_Fac;
+        if (Is_Cuspy)
+            rho += rho0_cc / (1 + (r / rc_cc) * (r / rc_cc)) / (1 + ((r / rcut) * (r / rcut) * (r / rcut)) * (r / rcut));
+    }
+    return rho;
 }
 
 /* wvt_relax.c:227-256 */
@@ -675,7 +693,7 @@ static inline float density_model(const orc_state *s, int ipart)
         double dy = y - h->d_com[1] - boxhalf;
         double dz = z - h->d_com[2] - boxhalf;
         double r2 = dx * dx + dy * dy + dz * dz;
-        double rho_i = gas_density_profile(sqrt(r2), h->rho0, h->beta, h->rcore, h->rcut);
+        double rho_i = gas_density_profile_c(sqrt(r2), h->rho0, h->beta, h->rcore, h->rcut, h->have_cuspy);
         rho = fmax(rho_i, rho);
     }
     return rho;
@@ -923,7 +941,7 @@ int orc_reassign_to_halos(int n, const float *pos, double boxsize, int nhalos, c
             float r = sqrt((x - halos[j].d_com[0]) * (x - halos[j].d_com[0])
                            + (y - halos[j].d_com[1]) * (y - halos[j].d_com[1])
                            + (z - halos[j].d_com[2]) * (z - halos[j].d_com[2]));
-            double rho_gas = gas_density_profile(r, halos[j].rho0, halos[j].beta, halos[j].rcore, halos[j].rcut);
+            double rho_gas = gas_density_profile_c(r, halos[j].rho0, halos[j].beta, halos[j].rcore, halos[j].rcut, halos[j].have_cuspy);
             if (rho_gas > rho_max && r < r_sample[j]) { i = j; rho_max = rho_gas; }
         }
         halo_id[ip] = i;
@@ -962,7 +980,7 @@ static int orc_halo_containing(int type, float x, float y, float z, double boxsi
         double rho_max = 0;
         for (int j = 0; j < nhalos; j++) {
             float r = sqrt(ORC_P2(x - Halo[j].d_com[0]) + ORC_P2(y - Halo[j].d_com[1]) + ORC_P2(z - Halo[j].d_com[2]));
-            double rho_gas = gas_density_profile(r, Halo[j].rho0, Halo[j].beta, Halo[j].rcore, Halo[j].rcut);
+            double rho_gas = gas_density_profile_c(r, Halo[j].rho0, Halo[j].beta, Halo[j].rcore, Halo[j].rcut, Halo[j].have_cuspy);
             if ((rho_gas > rho_max) && (r < r_sample_gas[j])) {
                 i = j;
                 rho_max = rho_gas;
@@ -984,7 +1002,7 @@ void orc_set_vector_potential(int n, const float *pos, double boxsize, int nhalo
             float dx = pos[3 * ipart] - Halo[i].d_com[0] - boxhalf, dy = pos[3 * ipart + 1] - Halo[i].d_com[1] - boxhalf,
                   dz = pos[3 * ipart + 2] - Halo[i].d_com[2] - boxhalf;
             double r2 = dx * dx + dy * dy + dz * dz;
-            double rho_i = gas_density_profile(sqrt(r2), Halo[i].rho0, Halo[i].beta, Halo[i].rcore, Halo[i].rcut);
+            double rho_i = gas_density_profile_c(sqrt(r2), Halo[i].rho0, Halo[i].beta, Halo[i].rcore, Halo[i].rcut, Halo[i].have_cuspy);
             double A = pow(rho_i / Halo[i].rho0, eta);
             if (A > A_max) A_max = A;
         }

@@ -38,9 +38,13 @@ typedef struct {
     double beta;         /* Halo[i].Beta */
     double rcore;        /* Halo[i].Rcore */
     double rcut;         /* Halo[i].Rcut */
-    int    have_cuspy;   /* Halo[i].Have_Cuspy (unused without DOUBLE_BETA_COOL_CORES) */
+    int    have_cuspy;   /* Halo[i].Have_Cuspy (read only by the DOUBLE_BETA_COOL_CORES variant, orc_set_double_beta) */
     int    pad_;
 } orc_halo;
+
+/* The reference's -DDOUBLE_BETA_COOL_CORES build as a run-time switch of the oracle: Param.Rho0_Fac, Param.Rc_Fac
+ * (globals.h:117-120); both 0 = the default build.  Process-wide, like the reference's Param. */
+void orc_set_double_beta(double rho0_fac, double rc_fac);
 
 typedef struct {
     int    it;

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(binding.TcParams) == 40
-    assert ctypes.sizeof(binding.TcHalo) == 72
+    assert ctypes.sizeof(binding.TcHalo) == 88      # 72 + rho0_cc, rc_cc (the -DDOUBLE_BETA_COOL_CORES component)
     assert ctypes.sizeof(binding.TcIterLog) == 40
     assert ctypes.sizeof(binding.TcDensityStats) == 32
 

@@ -30,7 +30,17 @@ class TcParams(C.Structure):
 
 class TcHalo(C.Structure):
     _fields_ = [("mass_gas", C.c_double), ("d_com", C.c_double * 3), ("rho0", C.c_double), ("beta", C.c_double),
-                ("rcore", C.c_double), ("rcut", C.c_double), ("have_cuspy", C.c_int32), ("reserved", C.c_int32)]
+                ("rcore", C.c_double), ("rcut", C.c_double), ("have_cuspy", C.c_int32), ("reserved", C.c_int32),
+                ("rho0_cc", C.c_double), ("rc_cc", C.c_double)]
+
+
+def cool_core_component(model, h):
+    """(rho0_cc, rc_cc) of the reference's -DDOUBLE_BETA_COOL_CORES build (src/setup.c:604-612): set for halos with
+    Have_Cuspy when the model carries Param.Rho0_Fac / Param.Rc_Fac; (0, 0) -- the default build -- otherwise."""
+    f_rho, f_rc = getattr(model, "rho0_fac", 0.0), getattr(model, "rc_fac", 0.0)
+    if f_rho and f_rc and getattr(h, "have_cuspy", 0):
+        return h.rho0 * f_rho, h.rcore / f_rc
+    return 0.0, 0.0
 
 
 class TcIterLog(C.Structure):
@@ -182,6 +192,7 @@ class TcGpu:
                 halos[k].d_com[c] = h.d_com[c]
             halos[k].rho0, halos[k].beta, halos[k].rcore, halos[k].rcut = h.rho0, h.beta, h.rcore, h.rcut
             halos[k].have_cuspy = int(h.have_cuspy)
+            halos[k].rho0_cc, halos[k].rc_cc = cool_core_component(model, h)
         self._ck(self._L.tcgpu_set_model(self._h, C.byref(par), halos))
         self.model = model
 

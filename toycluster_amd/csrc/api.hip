@@ -204,6 +204,8 @@ extern "C" int tcgpu_set_model(tcgpu_ctx *c, const tcgpu_params *par, const tcgp
         h[i].cx = halos[i].d_com[0]; h[i].cy = halos[i].d_com[1]; h[i].cz = halos[i].d_com[2];
         h[i].rho0 = halos[i].rho0; h[i].beta = halos[i].beta; h[i].rcore = halos[i].rcore; h[i].rcut = halos[i].rcut;
         h[i].mass_gas = halos[i].mass_gas;
+        h[i].rho0_cc = halos[i].rho0_cc; h[i].rc_cc = halos[i].rc_cc;
+        if (h[i].rho0_cc != 0 && !(h[i].rc_cc > 0)) { free(h); TC_FAIL(c, TCGPU_ERR_ARG, "halo %d: rho0_cc set but rc_cc <= 0", i); }
     }
     hipError_t e = hipMemcpy(c->d_halo, h, sizeof(tc_halo_dev) * par->nhalos, hipMemcpyHostToDevice);
     free(h);

@@ -257,13 +257,19 @@ typedef struct {
     double cx, cy, cz;   /* D_CoM + boxhalf is NOT pre-added: see tc_density_model */
     double rho0, beta, rcore, rcut;
     double mass_gas;
+    double rho0_cc, rc_cc;   /* -DDOUBLE_BETA_COOL_CORES component of a cuspy halo (tcgpu_halo); rho0_cc == 0: none */
 } tc_halo_dev;
 
-/* setup.c:598-615 (Makefile default: no DOUBLE_BETA_COOL_CORES) */
-TC_HD double tc_gas_density_profile(double r, double rho0, double beta, double rc, double rcut)
+/* setup.c:598-615.  The reference's default build has no cool-core term (rho0_cc == 0); its
+ * -DDOUBLE_BETA_COOL_CORES build adds  rho0_cc / (1 + (r/rc_cc)^2) / (1 + (r/rcut)^4)  for halos with Is_Cuspy */
+TC_HD double tc_gas_density_profile(double r, double rho0, double beta, double rc, double rcut, double rho0_cc,
+                                    double rc_cc)
 {
-    return rho0 * pow(1 + (r / rc) * (r / rc), -3.0 / 2.0 * beta)
-           / (1 + ((r / rcut) * (r / rcut) * (r / rcut)) * (r / rcut));
+    double rho = rho0 * pow(1 + (r / rc) * (r / rc), -3.0 / 2.0 * beta)
+                 / (1 + ((r / rcut) * (r / rcut) * (r / rcut)) * (r / rcut));
+    if (rho0_cc != 0)
+        rho += rho0_cc / (1 + (r / rc_cc) * (r / rc_cc)) / (1 + ((r / rcut) * (r / rcut) * (r / rcut)) * (r / rcut));
+    return rho;
 }
 
 /* wvt_relax.c:227-256 */
@@ -277,7 +283,8 @@ TC_HD float tc_density_model(float px, float py, float pz, double boxhalf, const
         double dy = y - halo[i].cy - boxhalf;
         double dz = z - halo[i].cz - boxhalf;
         double r2 = dx * dx + dy * dy + dz * dz;
-        double rho_i = tc_gas_density_profile(sqrt(r2), halo[i].rho0, halo[i].beta, halo[i].rcore, halo[i].rcut);
+        double rho_i = tc_gas_density_profile(sqrt(r2), halo[i].rho0, halo[i].beta, halo[i].rcore, halo[i].rcut,
+                                              halo[i].rho0_cc, halo[i].rc_cc);
         rho = fmax(rho_i, rho);
     }
     return (float)rho;

@@ -25,8 +25,7 @@
 
 static double gas_profile(double r, const tcgpu_halo *h)       /* src/setup.c:598-615 */
 {
-    const double a = r / h->rcore, b = r / h->rcut;
-    return h->rho0 * pow(1 + a * a, -3.0 / 2.0 * h->beta) / (1 + (b * b * b) * b);
+    return tc_host_gas_profile(r, h->rho0, h->beta, h->rcore, h->rcut, h->rho0_cc, h->rc_cc);
 }
 
 /* src/magnetic_field.c:33-69: A = max over gas halos of (rho_i(r) / rho0_i)^eta, same value on all three components */

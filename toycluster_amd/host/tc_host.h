@@ -14,6 +14,7 @@
 #define TC_HOST_H
 
 #include <stdint.h>
+#include <math.h>
 #include <stdio.h>
 #include "../../include/tcgpu.h"
 
@@ -33,6 +34,10 @@ typedef struct {
     double bfld_eta;                  /* Bfld_Eta */
     double baryon_fraction;           /* bf */
     double unit_length, unit_mass, unit_vel;   /* UnitLength_in_cm, UnitMass_in_g, UnitVelocity_in_cm_per_s */
+    /* the reference's -DDOUBLE_BETA_COOL_CORES build (Makefile:11) as a run-time switch: TC_DOUBLE_BETA=1 in the
+     * environment makes the two tags mandatory (src/io.c:435-443) and switches the cool-core component on */
+    int    double_beta, pad_;
+    double rho0_fac, rc_fac;          /* Rho0_Fac, Rc_Fac */
 } tc_parfile;
 
 /* 0 on success; 1 = file not found, 2 = a tag is missing (both fatal in the reference: exit(1)).
@@ -87,7 +92,22 @@ typedef struct {                      /* the fields of the reference's HaloPrope
     double d_com[3];
     long long npart[2];
     int have_cuspy, is_stripped;
+    double rho0_cc, rc_cc;            /* cool-core component (src/setup.c:604-612), 0 without -DDOUBLE_BETA_COOL_CORES */
 } tc_halo_setup;
+
+/* src/setup.c:598-615: the beta model with its r^4 cut-off, plus the -DDOUBLE_BETA_COOL_CORES component when
+ * rho0_cc != 0 (a halo with Is_Cuspy in that build) */
+static inline double tc_host_gas_profile(double r, double rho0, double beta, double rcore, double rcut, double rho0_cc,
+                                         double rc_cc)
+{
+    const double a = r / rcore, b = r / rcut;
+    double rho = rho0 * pow(1 + a * a, -3.0 / 2.0 * beta) / (1 + (b * b * b) * b);
+    if (rho0_cc != 0) {
+        const double c = r / rc_cc;
+        rho += rho0_cc / (1 + c * c) / (1 + (b * b * b) * b);
+    }
+    return rho;
+}
 
 typedef struct {
     tc_parfile par;

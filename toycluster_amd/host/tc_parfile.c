@@ -22,9 +22,14 @@ int tc_read_param_file(const char *filename, tc_parfile *p, char *err, size_t er
         {"UnitLength_in_cm", T_REAL, &p->unit_length, 0},
         {"UnitMass_in_g", T_REAL, &p->unit_mass, 0},
         {"UnitVelocity_in_cm_per_s", T_REAL, &p->unit_vel, 0},
+        {"Rho0_Fac", T_REAL, &p->rho0_fac, 0},          /* -DDOUBLE_BETA_COOL_CORES only (src/io.c:435-443) */
+        {"Rc_Fac", T_REAL, &p->rc_fac, 0},
     };
-    const int nt = (int)(sizeof(tab) / sizeof(tab[0]));
+    const int nt_all = (int)(sizeof(tab) / sizeof(tab[0]));
     memset(p, 0, sizeof(*p));
+    const char *db = getenv("TC_DOUBLE_BETA");
+    p->double_beta = db && atoi(db) != 0;
+    const int nt = p->double_beta ? nt_all : nt_all - 2;   /* the default build does not know the two tags */
 
     FILE *fd = fopen(filename, "r");
     if (!fd) {

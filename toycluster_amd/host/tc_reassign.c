@@ -16,11 +16,9 @@
 #include <string.h>
 #include "tc_host.h"
 
-/* src/setup.c:598-615 (no cool-core term: Makefile default) */
-static double gas_profile(double r, const tcgpu_halo *h)
+static double gas_profile(double r, const tcgpu_halo *h)       /* src/setup.c:598-615 */
 {
-    const double a = r / h->rcore, b = r / h->rcut;
-    return h->rho0 * pow(1 + a * a, -3.0 / 2.0 * h->beta) / (1 + (b * b * b) * b);
+    return tc_host_gas_profile(r, h->rho0, h->beta, h->rcore, h->rcut, h->rho0_cc, h->rc_cc);
 }
 
 /* Gas branch of Halo_containing: x, y, z are relative to the box centre (src/positions.c:273-275).

@@ -38,8 +38,20 @@
 
 static double profile(double r, const tc_halo_setup *h)      /* src/setup.c:598-615 */
 {
-    double a = r / h->rcore, b = r / h->rcut;
-    return h->rho0 * pow(1 + a * a, -3.0 / 2.0 * h->beta) / (1 + (b * b * b) * b);
+    /* the cool-core component scales with rho0 (rho0_cc = rho0 * Rho0_Fac), and rho0 is still being normalised when
+     * the mass profile is first built: the factor is carried in rho0_cc / rho0 form by the callers (set_cool_core) */
+    return tc_host_gas_profile(r, h->rho0, h->beta, h->rcore, h->rcut, h->rho0_cc, h->rc_cc);
+}
+
+/* src/setup.c:604-612: rho0_cc = rho0 * Param.Rho0_Fac, rc_cc = rc / Param.Rc_Fac for a cuspy halo of the
+ * -DDOUBLE_BETA_COOL_CORES build; to be called whenever rho0 or rcore of the halo changes */
+static void set_cool_core(const tc_parfile *par, tc_halo_setup *h)
+{
+    h->rho0_cc = h->rc_cc = 0;
+    if (par->double_beta && h->have_cuspy) {
+        h->rho0_cc = h->rho0 * par->rho0_fac;
+        h->rc_cc = h->rcore / par->rc_fac;
+    }
 }
 
 static double m_integrand(double r, const tc_halo_setup *h) { return 4 * PI * r * r * profile(r, h); }
@@ -180,13 +192,17 @@ int tc_setup_system(const tc_parfile *par, tc_setup *S)
             H[i].r_sample[1] = S->boxsize / 2;
             H[i].r_sample[0] = sqrt(3) * S->boxsize / 2;
         }
-        if (par->cuspy & (1 << i)) { H[i].rcore = H[i].rs / 9; H[i].have_cuspy = 1; }   /* src/setup.c:567-589 */
-        else { H[i].rcore = H[i].rs / 3; H[i].have_cuspy = 0; }
+        if (par->cuspy & (1 << i)) {                                                      /* src/setup.c:567-589 */
+            H[i].rcore = H[i].rs / (par->double_beta ? 3 : 9);                            /* :583-587 */
+            H[i].have_cuspy = 1;
+        } else { H[i].rcore = H[i].rs / 3; H[i].have_cuspy = 0; }
 
         mass_profile_t mp;
         H[i].rho0 = 1;
+        set_cool_core(par, &H[i]);
         setup_mass_profile(&H[i], &mp);
         H[i].rho0 = H[i].mass200[0] / mass_profile(&mp, &H[i], H[i].r200);
+        set_cool_core(par, &H[i]);
         spline_free(&mp.m_of_r); spline_free(&mp.r_of_m);
         setup_mass_profile(&H[i], &mp);
         H[i].mass[0] = mass_profile(&mp, &H[i], H[i].r_sample[0]);
@@ -235,6 +251,7 @@ void tc_setup_to_model(const tc_setup *S, tcgpu_params *par, tcgpu_halo *halos)
         halos[i].rho0 = S->halo[i].rho0; halos[i].beta = S->halo[i].beta;
         halos[i].rcore = S->halo[i].rcore; halos[i].rcut = S->halo[i].rcut;
         halos[i].have_cuspy = S->halo[i].have_cuspy;
+        halos[i].rho0_cc = S->halo[i].rho0_cc; halos[i].rc_cc = S->halo[i].rc_cc;
     }
 }
 
@@ -419,10 +436,13 @@ static void set_subhalo_properties(tc_setup *S, int i)                          
     h->mtotal200 = h->mass200[0] + h->mass200[1];
     h->mass_corr_fac = 1 / (1 + 2 * a / r200 + (a / r200) * (a / r200));
     h->beta = 2.0 / 3.0;
-    if (i < 31 && (S->par.cuspy & (1 << i))) { h->rcore = h->rs / 9; h->have_cuspy = 1; }   /* src/setup.c:567-589 */
-    else { h->rcore = h->rs / 3; h->have_cuspy = 0; }
+    if (i < 31 && (S->par.cuspy & (1 << i))) {                                              /* src/setup.c:567-589 */
+        h->rcore = h->rs / (S->par.double_beta ? 3 : 9);
+        h->have_cuspy = 1;
+    } else { h->rcore = h->rs / 3; h->have_cuspy = 0; }
     const double rc = h->rcore;
     h->rho0 = h->mass200[0] / (4 * PI * (rc * rc * rc)) / (r200 / rc - atan(r200 / rc));
+    set_cool_core(&S->par, h);
     h->mass[0] = 0;
     h->is_stripped = 1;
     if (r_i > r_strip) {

@@ -1,6 +1,6 @@
 /* tc_state.c -- the hot-path state file: everything Regularise_sph_particles() reads besides the
  * per-particle SPH fields.  Little-endian, fixed layout:
- *   char magic[8] = "TCSTATE1"; int64 ngas; tcgpu_params par; tcgpu_halo halos[par.nhalos];
+ *   char magic[8] = "TCSTATE2" (2: tcgpu_halo carries the cool-core component); int64 ngas; tcgpu_params par; tcgpu_halo halos[par.nhalos];
  *   float pos[3*ngas]; int32 id[ngas]
  *   optional trailer: double r_sample[par.nhalos]  (Halo[i].R_Sample[0]; only the halo reassignment
  *   behind the path reads it, src/positions.c:378)
@@ -9,7 +9,7 @@
 #include <string.h>
 #include "tc_host.h"
 
-static const char MAGIC[8] = {'T', 'C', 'S', 'T', 'A', 'T', 'E', '1'};
+static const char MAGIC[8] = {'T', 'C', 'S', 'T', 'A', 'T', 'E', '2'};
 
 void tc_free_state(tc_state *st)
 {

@@ -6,7 +6,7 @@ import struct
 
 import numpy as np
 
-from .binding import TcHalo, TcParams
+from .binding import TcHalo, TcParams, cool_core_component
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOSTLIB = os.path.join(_HERE, "lib", "libtchost.so")
@@ -19,7 +19,8 @@ class ParFile(C.Structure):
                 ("redshift", C.c_double), ("mass_ratio", C.c_double), ("impact_param", C.c_double),
                 ("zero_e_orbit_frac", C.c_double), ("cuspy", C.c_int), ("bfld_norm", C.c_double),
                 ("bfld_eta", C.c_double), ("baryon_fraction", C.c_double), ("unit_length", C.c_double),
-                ("unit_mass", C.c_double), ("unit_vel", C.c_double)]
+                ("unit_mass", C.c_double), ("unit_vel", C.c_double), ("double_beta", C.c_int), ("pad_", C.c_int),
+                ("rho0_fac", C.c_double), ("rc_fac", C.c_double)]
 
 
 class Snapshot(C.Structure):
@@ -34,7 +35,8 @@ class HaloSetup(C.Structure):
                 ("rs", C.c_double), ("a_hernq", C.c_double), ("rho0", C.c_double), ("beta", C.c_double),
                 ("rcore", C.c_double), ("rcut", C.c_double), ("r_sample", C.c_double * 2), ("mass", C.c_double * 2),
                 ("mtotal", C.c_double), ("mass_corr_fac", C.c_double), ("d_com", C.c_double * 3),
-                ("npart", C.c_longlong * 2), ("have_cuspy", C.c_int), ("is_stripped", C.c_int)]
+                ("npart", C.c_longlong * 2), ("have_cuspy", C.c_int), ("is_stripped", C.c_int),
+                ("rho0_cc", C.c_double), ("rc_cc", C.c_double)]
 
 
 class Setup(C.Structure):
@@ -100,8 +102,10 @@ def setup_to_model(setup):
         h = setup.halo[i]
         halos.append(Halo(rho0=h.rho0, beta=h.beta, rcore=h.rcore, rcut=h.rcut, d_com=tuple(h.d_com),
                           r_sample=h.r_sample[0], mass_gas=h.mass[0], have_cuspy=h.have_cuspy))
+    db = bool(setup.par.double_beta)
     return ClusterModel(boxsize=setup.boxsize, halos=halos, mpart_gas=setup.mpart[0], mtotal=setup.mtotal,
-                        bfld_eta=setup.par.bfld_eta, name="native-setup")
+                        bfld_eta=setup.par.bfld_eta, name="native-setup",
+                        rho0_fac=setup.par.rho0_fac if db else 0.0, rc_fac=setup.par.rc_fac if db else 0.0)
 
 
 def _lib():
@@ -175,7 +179,7 @@ def write_state(path, model, pos, ids):
     ids = np.ascontiguousarray(ids, dtype=np.int32)
     par = TcParams(model.boxsize, model.mpart_gas, model.mtotal, getattr(model, "bfld_eta", 0.5), len(model.halos), 0)
     with open(path, "wb") as f:
-        f.write(b"TCSTATE1")
+        f.write(b"TCSTATE2")
         f.write(struct.pack("<q", len(ids)))
         f.write(bytes(par))
         for h in model.halos:
@@ -184,6 +188,7 @@ def write_state(path, model, pos, ids):
             for c in range(3):
                 th.d_com[c] = h.d_com[c]
             th.rho0, th.beta, th.rcore, th.rcut, th.have_cuspy = h.rho0, h.beta, h.rcore, h.rcut, int(h.have_cuspy)
+            th.rho0_cc, th.rc_cc = cool_core_component(model, h)
             f.write(bytes(th))
         f.write(pos.tobytes())
         f.write(ids.tobytes())
@@ -200,6 +205,7 @@ def _model_structs(model):
             halos[k].d_com[c] = h.d_com[c]
         halos[k].rho0, halos[k].beta, halos[k].rcore, halos[k].rcut = h.rho0, h.beta, h.rcore, h.rcut
         halos[k].have_cuspy = int(h.have_cuspy)
+        halos[k].rho0_cc, halos[k].rc_cc = cool_core_component(model, h)
     return par, halos
 
 

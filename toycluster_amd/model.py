@@ -41,16 +41,22 @@ class ClusterModel:
     mtotal: float = 2.0e5      # Param.Mtotal (only the `< 1e5` test of wvt_relax.c:53 reads it)
     bfld_eta: float = 0.5
     name: str = ""
+    rho0_fac: float = 0.0      # Param.Rho0_Fac / Param.Rc_Fac of the reference's -DDOUBLE_BETA_COOL_CORES build
+    rc_fac: float = 0.0        # (0 = the default build: no cool-core component)
 
     @property
     def nhalos(self):
         return len(self.halos)
 
 
-def gas_density_profile(r, h: Halo):
-    """setup.c:598-615 (beta model with r^4 cut-off; no cool-core term: Makefile default)."""
+def gas_density_profile(r, h: Halo, rho0_fac=0.0, rc_fac=0.0):
+    """setup.c:598-615 (beta model with r^4 cut-off; the cool-core term of -DDOUBLE_BETA_COOL_CORES only when the
+    factors are given and the halo is cuspy)."""
     r = np.asarray(r, dtype=np.float64)
-    return h.rho0 * (1 + (r / h.rcore) ** 2) ** (-1.5 * h.beta) / (1 + (r / h.rcut) ** 4)
+    rho = h.rho0 * (1 + (r / h.rcore) ** 2) ** (-1.5 * h.beta) / (1 + (r / h.rcut) ** 4)
+    if rho0_fac and rc_fac and h.have_cuspy:
+        rho = rho + h.rho0 * rho0_fac / (1 + (r / (h.rcore / rc_fac)) ** 2) / (1 + (r / h.rcut) ** 4)
+    return rho
 
 
 def _mass_table(h: Halo, rmax, npts=20000):
