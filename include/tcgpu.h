@@ -32,8 +32,15 @@
 extern "C" {
 #endif
 
+/* -DTCGPU_SPH_CUBIC_SPLINE: the library build that restates the reference's -DSPH_CUBIC_SPLINE build (Makefile:25:
+ * M4 kernel, 50 neighbours; libtcgpu_m4.so, `make -C toycluster_amd/csrc m4`).  A compile-time choice there and here. */
+#ifdef TCGPU_SPH_CUBIC_SPLINE
+#define TCGPU_DESNNGB 50       /* src/globals.h:42 */
+#define TCGPU_NGBMAX  400      /* src/globals.h:44 */
+#else
 #define TCGPU_DESNNGB 295      /* src/globals.h:48 */
 #define TCGPU_NGBMAX  2360     /* src/globals.h:50 */
+#endif
 #define TCGPU_NUMITER 64       /* src/wvt_relax.c:7 */
 #define TCGPU_MAXLOG  (TCGPU_NUMITER + 2)
 

@@ -28,21 +28,22 @@ class OrcIterLog(C.Structure):
                 ("err_diff", C.c_double), ("step", C.c_double)]
 
 
-def build(force=False):
+def build(force=False, variant=""):
+    """variant "m4": the reference's -DSPH_CUBIC_SPLINE build (libtcoracle_m4.so)."""
     src = os.path.join(_HERE, "tc_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "libtcoracle.so"], stdout=subprocess.DEVNULL)
-    return _LIB
+    path = _LIB if not variant else _LIB.replace(".so", "_%s.so" % variant)
+    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(path)], stdout=subprocess.DEVNULL)
+    return path
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
+def lib(variant=""):
+    _lib = _libs.get(variant)
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB)
+        L = C.CDLL(build(variant=variant))
         vp, ci, cd, cf = C.c_void_p, C.c_int, C.c_double, C.c_float
         L.orc_create.restype = vp
         L.orc_create.argtypes = [ci, cd, cd, cd, ci, C.POINTER(OrcHalo), ci]
@@ -75,7 +76,7 @@ def lib():
         L.orc_last_stats.argtypes = [vp, C.POINTER(cd), C.POINTER(cd), C.POINTER(cd)]
         L.orc_reassign_to_halos.argtypes = [ci, vp, cd, ci, C.POINTER(OrcHalo), vp, vp, vp, vp]
         L.orc_reassign_to_halos.restype = ci
-        _lib = L
+        _libs[variant] = _lib = L
     return _lib
 
 
@@ -107,9 +108,10 @@ def set_double_beta(rho0_fac=0.0, rc_fac=0.0):
 class Oracle:
     """State handle mirroring the reference's globals P / SphP / Param / Halo for the gas particles."""
 
-    def __init__(self, model, pos, ids=None, hsml=None, nthreads=0):
+    def __init__(self, model, pos, ids=None, hsml=None, nthreads=0, variant=""):
         """model: any object with boxsize, mpart_gas, mtotal and halos (list of dicts/objs with
         mass_gas, d_com, rho0, beta, rcore, rcut, have_cuspy)."""
+        self._L = lib(variant)                    # "m4": the -DSPH_CUBIC_SPLINE build of the oracle
         pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
         self.n = pos.shape[0]
         halos = (OrcHalo * len(model.halos))()
@@ -121,15 +123,15 @@ class Oracle:
             halos[k].rho0, halos[k].beta = g("rho0"), g("beta")
             halos[k].rcore, halos[k].rcut = g("rcore"), g("rcut")
             halos[k].have_cuspy = int(g("have_cuspy"))
-        self._h = lib().orc_create(self.n, model.boxsize, model.mpart_gas, model.mtotal,
+        self._h = self._L.orc_create(self.n, model.boxsize, model.mpart_gas, model.mtotal,
                                    len(model.halos), halos, nthreads)
         ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
         hsml = None if hsml is None else np.ascontiguousarray(hsml, dtype=np.float32)
-        lib().orc_set_particles(self._h, _p(pos), _p(ids), _p(hsml))
+        self._L.orc_set_particles(self._h, _p(pos), _p(ids), _p(hsml))
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+            self._L.orc_destroy(self._h)
             self._h = None
 
     def particles(self):
@@ -137,59 +139,59 @@ class Oracle:
         out = dict(pos=np.empty((n, 3), np.float32), id=np.empty(n, np.int32), hsml=np.empty(n, np.float32),
                    rho=np.empty(n, np.float32), varhsmlfac=np.empty(n, np.float32),
                    rho_model=np.empty(n, np.float32))
-        lib().orc_get_particles(self._h, _p(out["pos"]), _p(out["id"]), _p(out["hsml"]), _p(out["rho"]),
+        self._L.orc_get_particles(self._h, _p(out["pos"]), _p(out["id"]), _p(out["hsml"]), _p(out["rho"]),
                                 _p(out["varhsmlfac"]), _p(out["rho_model"]))
         return out
 
     def sort_by_peano_key(self):
         n = self.n
         hi, lo, perm = np.empty(n, np.uint64), np.empty(n, np.uint64), np.empty(n, np.int64)
-        lib().orc_sort_by_peano_key(self._h, _p(hi), _p(lo), _p(perm))
+        self._L.orc_sort_by_peano_key(self._h, _p(hi), _p(lo), _p(perm))
         return hi, lo, perm
 
     def build_tree(self):
-        return lib().orc_build_tree(self._h)
+        return self._L.orc_build_tree(self._h)
 
     def tree_nodes(self):
-        nn = lib().orc_tree_nodes(self._h, None, None, None, None, None, None)
+        nn = self._L.orc_tree_nodes(self._h, None, None, None, None, None, None)
         out = dict(bitfield=np.empty(nn, np.uint32), dnext=np.empty(nn, np.int32), pos=np.empty((nn, 3), np.float32),
                    npart=np.empty(nn, np.int32), size=np.empty(nn, np.float32),
                    tree_parent=np.empty(self.n, np.int32))
-        lib().orc_tree_nodes(self._h, _p(out["bitfield"]), _p(out["dnext"]), _p(out["pos"]), _p(out["npart"]),
+        self._L.orc_tree_nodes(self._h, _p(out["bitfield"]), _p(out["dnext"]), _p(out["pos"]), _p(out["npart"]),
                              _p(out["size"]), _p(out["tree_parent"]))
         return out
 
     def find_ngb_tree(self, ipart, hsml):
         buf = np.empty(NGBMAX, np.int32)
-        c = lib().orc_find_ngb_tree(self._h, int(ipart), float(np.float32(hsml)), _p(buf))
+        c = self._L.orc_find_ngb_tree(self._h, int(ipart), float(np.float32(hsml)), _p(buf))
         return buf[:c].copy()
 
     def find_ngb_simple(self, ipart, hsml):
         buf = np.empty(NGBMAX, np.int32)
-        c = lib().orc_find_ngb_simple(self._h, int(ipart), float(np.float32(hsml)), _p(buf))
+        c = self._L.orc_find_ngb_simple(self._h, int(ipart), float(np.float32(hsml)), _p(buf))
         return buf[:c].copy()
 
     def guess_hsml(self, ipart):
-        return np.float32(lib().orc_guess_hsml(self._h, int(ipart)))
+        return np.float32(self._L.orc_guess_hsml(self._h, int(ipart)))
 
     def find_sph_quantities(self):
-        rc = lib().orc_find_sph_quantities(self._h)
+        rc = self._L.orc_find_sph_quantities(self._h)
         if rc < 0:
             raise RuntimeError("oracle find_sph_quantities failed rc=%d" % rc)
 
     def last_stats(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
-        lib().orc_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        self._L.orc_last_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
         return dict(queries=a.value, solver_iters=b.value, pair_evals=c.value)
 
     def global_density_model(self):
         out = np.empty(self.n, np.float32)
-        lib().orc_global_density_model(self._h, _p(out))
+        self._L.orc_global_density_model(self._h, _p(out))
         return out
 
     def regularise(self, max_iter=-1):
         log = (OrcIterLog * MAXLOG)()
-        nlog = lib().orc_regularise(self._h, log, max_iter)
+        nlog = self._L.orc_regularise(self._h, log, max_iter)
         if nlog < 0:
             raise RuntimeError("oracle regularise failed")
         return [dict(it=l.it, err_max=l.err_max, err_mean=l.err_mean, err_diff=l.err_diff, step=l.step)
@@ -198,17 +200,17 @@ class Oracle:
     def wvt_step(self, step, move=True):
         hs = np.empty(self.n, np.float32)
         de = np.empty((self.n, 3), np.float32)
-        lib().orc_wvt_step(self._h, float(step), _p(hs), _p(de), int(bool(move)))
+        self._L.orc_wvt_step(self._h, float(step), _p(hs), _p(de), int(bool(move)))
         return hs, de
 
     def set_apot(self, a):
         a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)
-        lib().orc_set_apot(self._h, _p(a))
+        self._L.orc_set_apot(self._h, _p(a))
 
     def bfld_from_rotA(self):
-        lib().orc_bfld_from_rotA(self._h)
+        self._L.orc_bfld_from_rotA(self._h)
         b = np.empty((self.n, 3), np.float32)
-        lib().orc_get_bfld(self._h, _p(b))
+        self._L.orc_get_bfld(self._h, _p(b))
         return b
 
 

@@ -526,8 +526,41 @@ static inline float dwc6(const float r, const float h)
            * (16 * u * u + 7 * u + 1);
 }
 
+/* sph.c:442-466 (cubic spline, -DSPH_CUBIC_SPLINE) */
+static inline float sph_kernel_M4(const float r, const float h)
+{
+    double wk = 0;
+    double u = r / h;
+    if (u < 0.5)
+        wk = (2.546479089470 + 15.278874536822 * (u - 1) * u * u);
+    else
+        wk = 5.092958178941 * (1.0 - u) * (1.0 - u) * (1.0 - u);
+    return wk / (h * h * h);
+}
+
+static inline float sph_kernel_derivative_M4(const float r, const float h)
+{
+    double dwk = 0;
+    double u = r / h;
+    if (u < 0.5)
+        dwk = u * (45.836623610466 * u - 30.557749073644);
+    else
+        dwk = (-15.278874536822) * (1.0 - u) * (1.0 - u);
+    return dwk / (h * h * h * h);
+}
+
+#ifdef ORC_SPH_CUBIC_SPLINE                       /* sph.c:140-146, :374-378 */
+#define sph_w(r, h) sph_kernel_M4(r, h)
+#define sph_dw(r, h) sph_kernel_derivative_M4(r, h)
+#else
+#define sph_w(r, h) wc6(r, h)
+#define sph_dw(r, h) dwc6(r, h)
+#endif
+
 float orc_wc6(float r, float h) { return wc6(r, h); }
 float orc_dwc6(float r, float h) { return dwc6(r, h); }
+float orc_m4(float r, float h) { return sph_kernel_M4(r, h); }
+float orc_dm4(float r, float h) { return sph_kernel_derivative_M4(r, h); }
 
 /* sph.c:80-214 */
 static bool find_hsml(const orc_state *s, int ipart, const int32_t *ngblist, int ngbcnt,
@@ -567,8 +600,8 @@ static bool find_hsml(const orc_state *s, int ipart, const int32_t *ngblist, int
             double r2 = dx * dx + dy * dy + dz * dz;
             if (r2 > hsml * hsml) continue;
             double r = sqrt(r2);
-            double wk = wc6(r, hsml);
-            double dwk = dwc6(r, hsml);
+            double wk = sph_w(r, hsml);
+            double dwk = sph_dw(r, hsml);
             wkNgb += ORC_FOURPITHIRD * wk * (hsml * hsml * hsml);
             rho += mpart * wk;
             dRhodHsml += -mpart * (3 / hsml * wk + r / hsml * dwk);
@@ -597,11 +630,13 @@ static bool find_hsml(const orc_state *s, int ipart, const int32_t *ngblist, int
     *hsml_out = (float)hsml;
     *rho_out = (float)rho;
 
+#ifndef ORC_SPH_CUBIC_SPLINE                      /* sph.c:201-212 */
     if (part_done) {
         *dRhodHsml_out = (float)dRhodHsml;
         double bias_corr = -0.0116 * pow(ORC_DESNNGB * 0.01, -2.236) * mpart * wc6(0, hsml);
         *rho_out += bias_corr;
     }
+#endif
     return part_done;
 }
 
@@ -794,8 +829,12 @@ int orc_regularise(orc_state *s, orc_iterlog *log, int max_iter)
 {
     const int n = s->n;
     int it = -1, nlog = 0;
+#ifdef ORC_SPH_CUBIC_SPLINE                       /* wvt_relax.c:48-56 */
+    double step = 0.035;
+#else
     double step = 0.0085;
     if (s->mtotal < 1e5) step /= 2;
+#endif
     double errLast = DBL_MAX, errDiff = DBL_MAX, errDiffLast = DBL_MAX;
     const int numiter = max_iter >= 0 ? max_iter : ORC_NUMITER;
 
@@ -867,7 +906,7 @@ void orc_bfld_from_rotA(orc_state *s)
             double r2 = dx * dx + dy * dy + dz * dz;
             if (r2 > hsml * hsml) continue;
             double r = sqrt(r2);
-            double dwk = dwc6(r, hsml);
+            double dwk = sph_dw(r, hsml);
             double weight = -mpart / rho_i * dwk / r * varHsmlFac;
             double dAx = a0 - s->apot[3 * j];
             double dAy = a1 - s->apot[3 * j + 1];

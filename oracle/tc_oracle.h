@@ -24,7 +24,13 @@
 #include <stdint.h>
 #include <stddef.h>
 
+/* -DORC_SPH_CUBIC_SPLINE = the reference's -DSPH_CUBIC_SPLINE build (Makefile:25; globals.h:40-52): M4 kernel with 50
+ * neighbours in the density solve and the curl, no bias correction, WVT step 0.035.  Built as libtcoracle_m4.so. */
+#ifdef ORC_SPH_CUBIC_SPLINE
+#define ORC_DESNNGB 50           /* globals.h:42 */
+#else
 #define ORC_DESNNGB 295          /* globals.h:48 */
+#endif
 #define ORC_NNGBDEV 0.05         /* globals.h:49 */
 #define ORC_NGBMAX (ORC_DESNNGB * 8)   /* globals.h:50 */
 #define ORC_NUMITER 64           /* wvt_relax.c:7 */

@@ -271,6 +271,64 @@ def test_double_beta_cool_core_variant(gpu):
     assert rel(a[1:], b[1:]).max() < 2e-7
 
 
+def test_cubic_spline_variant_vs_oracle():
+    """libtcgpu_m4.so, the library build that restates the reference's -DSPH_CUBIC_SPLINE build (Makefile:25: M4 kernel,
+    50 neighbours, NGBMAX 400, no bias correction, varHsmlFac = 1, WVT step 0.035), against the oracle built the same
+    way (libtcoracle_m4.so): cold density pass, three relaxation iterations, the SPH curl.  Parity unpinned."""
+    n = 30000
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=11)
+    o = O.Oracle(m, pos, ids, nthreads=8, variant="m4")
+    o.find_sph_quantities()
+    po = o.particles()
+    g = binding.TcGpu(0, variant="m4")
+    try:
+        assert b"CUBIC_SPLINE" in g._L.tcgpu_version()
+        g.set_model(m)
+        g.upload(pos, ids)
+        g.set_option("stats", 1)
+        g.Find_sph_quantities()
+        pg = g.particles()
+        assert np.array_equal(pg["id"], po["id"])
+        assert rel(pg["hsml"], po["hsml"]).max() < 1e-6 and rel(pg["rho"], po["rho"]).max() < 1e-6
+        assert (pg["varhsmlfac"] == 1.0).all() and (po["varhsmlfac"] == 1.0).all()       # sph.c:201: dRhodHsml stays 0
+        # 50 +- 0.05 kernel-weighted neighbours (globals.h:42-43), by the reference's own formula on a sample
+        g.build_neighbour_index()
+        for i in range(0, n, n // 40):
+            ngb = g.Find_ngb_tree(i, pg["hsml"][i])
+            d = pg["pos"][ngb].astype(np.float64) - pg["pos"][i].astype(np.float64)
+            d -= m.boxsize * np.round(d / m.boxsize)
+            r = np.sqrt((d * d).sum(axis=1))
+            u = (r.astype(np.float32) / pg["hsml"][i]).astype(np.float64)
+            wk = np.where(u < 0.5, 2.546479089470 + 15.278874536822 * (u - 1) * u * u, 5.092958178941 * (1 - u) ** 3)
+            wk = np.where(u > 1, 0.0, wk)
+            assert abs(4.18879032135009765 * wk.sum() - 50) < 0.06, (i, 4.18879032135009765 * wk.sum())
+        # relaxation: same log (step 0.035, wvt_relax.c:48-49), same particles
+        g.upload(pos, ids)
+        log = g.Regularise_sph_particles(max_iter=3)
+        o = O.Oracle(m, pos, ids, nthreads=8, variant="m4")
+        want = o.regularise(max_iter=3)
+        assert len(log) == len(want) and all(l["step"] == 0.035 for l in log)
+        for a, b in zip(log, want):
+            assert a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-5) and a["err_max"] == pytest.approx(b["err_max"], rel=1e-4)
+        g.Find_sph_quantities()
+        o.find_sph_quantities()
+        pg, po = g.particles(), o.particles()
+        assert np.array_equal(pg["id"], po["id"])
+        assert (np.abs(pg["pos"] - po["pos"]).max(axis=1) / po["hsml"]).max() < TOL_POS
+        assert np.median(rel(pg["rho"], po["rho"])) < 1e-6
+        # curl of a smooth vector potential
+        rm = g.Global_density_model().astype(np.float64)
+        a = ((rm / max(h.rho0 for h in m.halos)) ** 0.5).astype(np.float32)
+        apot = np.stack([a, 0.5 * a, -a], axis=1)
+        b = g.Bfld_from_rotA_SPH(apot)
+        o.set_apot(apot)
+        bo = o.bfld_from_rotA()
+        assert np.abs(b - bo).max() < 1e-4 * np.abs(bo).max()
+    finally:
+        g.close()
+
+
 def test_density_pass_cold(gpu, golden_case):
     c = golden_case
     gpu.set_model(c["model"])

@@ -65,16 +65,18 @@ EXPORTS = [
     "tcgpu_phase_times", "tcgpu_stream", "tcgpu_comm_bytes", "tcgpu_local_set_info",
 ]
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Load libtcgpu.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
-    global _lib
+def lib(variant=""):
+    """Load libtcgpu.so (variant "m4": libtcgpu_m4.so, the build restating the reference's -DSPH_CUBIC_SPLINE build);
+    raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    _lib = _libs.get(variant)
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libtcgpu.so not built: %s missing (run __graft_entry__.build())" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+        path = LIB_PATH if not variant else LIB_PATH.replace(".so", "_%s.so" % variant)
+        if not os.path.exists(path):
+            raise RuntimeError("%s not built: %s missing (run __graft_entry__.build())" % (os.path.basename(path), path))
+        L = C.CDLL(path)
         vp, i32, i64, dbl, flt = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_float
         L.tcgpu_create.argtypes = [C.POINTER(vp), i32]
         L.tcgpu_destroy.argtypes = [vp]
@@ -113,7 +115,7 @@ def lib():
             L.tcgpu_debug_comm_selftest.restype = i32
         L.tcgpu_comm_bytes.restype = dbl
         L.tcgpu_local_set_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int32)]
-        _lib = L
+        _libs[variant] = _lib = L
     return _lib
 
 
@@ -147,8 +149,8 @@ def loopback_group(contexts):
 class TcGpu:
     """One context per GPU (the reference's globals, made explicit)."""
 
-    def __init__(self, device=0, rank=0, nranks=1, unique_id=None, options=None):
-        self._L = lib()
+    def __init__(self, device=0, rank=0, nranks=1, unique_id=None, options=None, variant=""):
+        self._L = lib(variant)
         h = C.c_void_p()
         rc = self._L.tcgpu_create(C.byref(h), int(device))
         if rc:

@@ -101,7 +101,11 @@ void tc_phase_collect(tcgpu_ctx *c)
 
 /* ------------------------------------------------------------------ life cycle */
 
+#ifdef TCGPU_SPH_CUBIC_SPLINE
+extern "C" const char *tcgpu_version(void) { return "tcgpu 0.2 (gfx950, -DSPH_CUBIC_SPLINE variant)"; }
+#else
 extern "C" const char *tcgpu_version(void) { return "tcgpu 0.2 (gfx950)"; }
+#endif
 
 extern "C" const char *tcgpu_last_error(const tcgpu_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
@@ -1276,8 +1280,12 @@ extern "C" int tcgpu_regularise_sph_particles(tcgpu_ctx *c, int max_iter, tcgpu_
     if (!c || c->n <= 0 || !c->have_model) return TCGPU_ERR_ARG;
     TC_HIP(c, hipSetDevice(c->device));
     int it = -1, nlog = 0;
+#ifdef TCGPU_SPH_CUBIC_SPLINE
+    double step = 0.035;                                      /* wvt_relax.c:48-49 */
+#else
     double step = 0.0085;                                     /* wvt_relax.c:51 */
     if (c->par.mtotal < 1e5) step /= 2;                       /* wvt_relax.c:53-54 */
+#endif
     double errLast = DBL_MAX, errDiff = DBL_MAX, errDiffLast = DBL_MAX;
     const int numiter = max_iter >= 0 ? max_iter : TCGPU_NUMITER;
     int rc;

@@ -800,6 +800,15 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
          * moves per entry otherwise) */
         double c25 = 25.0;
         asm volatile("; park %0" : "+v"(c25));
+#ifdef TCGPU_SPH_CUBIC_SPLINE
+        /* src/sph.c:140-146: the M4 kernel and its derivative as the reference writes them (tc_m4 / tc_dm4) */
+        auto term = [&](auto exact, double r, double &s0, double &s1) {
+            (void)exact; (void)c25; (void)norm_h3; (void)norm_h4;
+            const float rf = (float)r;
+            s0 += (double)tc_m4(rf, hf);
+            s1 = fma(r, (double)tc_dm4(rf, hf), s1);
+        };
+#else
         auto term = [&](auto exact, double r, double &s0, double &s1) {
             const float rf = (float)r;
             const float u = decltype(exact)::value ? rf / fd.b : tc_fdiv_apply_fast(fd, rf);
@@ -815,6 +824,7 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
             s0 += wk;
             s1 = fma(r, dwk, s1);
         };
+#endif
         /* two independent entries per lane and trip: the f64 chains are latency-bound otherwise.
          * `r > hsml` entries are skipped: == (r2 > hsml^2) up to a zero-weight boundary;
          * a skipped entry is evaluated at r = hsml, where u = 1, t = 0 and both kernels are exactly 0.
@@ -861,6 +871,7 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
 
     hsml_io = (float)hsml;
     rho_out = (float)rho;
+#ifndef TCGPU_SPH_CUBIC_SPLINE                   /* src/sph.c:201-212: neither with the cubic spline */
     if (part_done) {
         drho_io = (float)dRhodHsml;
         const float hf = (float)hsml;
@@ -869,6 +880,9 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         double bias_corr = bias_const * mpart * w0;
         rho_out = (float)((double)rho_out + bias_corr);
     }
+#else
+    (void)bias_const;
+#endif
     return part_done;
 }
 
@@ -1626,6 +1640,7 @@ __device__ __forceinline__ void curl_one_slow(const tc_curl_args &a, int i, uint
     const double hsml = hq, rho_i = a.rho[i], vhf = a.vhf[i];
     const double ax = a.apot[3 * (size_t)i], ay = a.apot[3 * (size_t)i + 1], az = a.apot[3 * (size_t)i + 2];
     const double norm_h4 = TC_WC6_NORM / (double)(hq * hq * hq * hq) * -22.0;
+    (void)norm_h4;                                           /* the cubic-spline build has its own normalisation */
     const double nm_rho = -k.mpart / rho_i;
     double b0 = 0, b1 = 0, b2 = 0;
     int cnt = 0;
@@ -1648,7 +1663,11 @@ __device__ __forceinline__ void curl_one_slow(const tc_curl_args &a, int i, uint
                 double r2 = dx * dx + dy * dy + dz * dz;
                 if (!(r2 > hsml * hsml)) {
                     double r = sqrt(r2);
+#ifdef TCGPU_SPH_CUBIC_SPLINE
+                    double dwk = tc_dm4((float)r, hq);                      /* src/sph.c:374-378 */
+#else
                     double dwk = tc_dwc6((float)r, hq, norm_h4);
+#endif
                     double weight = nm_rho * dwk / r * vhf;
                     double dAx = ax - (double)a.apot[3 * (size_t)j];
                     double dAy = ay - (double)a.apot[3 * (size_t)j + 1];
@@ -1700,6 +1719,7 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
     const double hsml = hq, rho_i = a.rho[i], vhf = a.vhf[i];
     const double ax = a.apot[3 * (size_t)i], ay = a.apot[3 * (size_t)i + 1], az = a.apot[3 * (size_t)i + 2];
     const double norm_h4 = TC_WC6_NORM / (double)(hq * hq * hq * hq) * -22.0;
+    (void)norm_h4;                                           /* the cubic-spline build has its own normalisation */
     const double wfac = -k.mpart / rho_i * vhf;             /* -m/rho_i * varHsmlFac (src/sph.c:282), dwk/r per pair */
     tc_fdiv fd = tc_fdiv_setup(hq);
     fd.exact_div = U(fd.exact_div);
@@ -1748,11 +1768,15 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
                     rinv = tc_rcp_f64_lean_nz(r);
                 }
                 /* sph_kernel_derivative_WC6 (src/sph.c:434-440): u = r/h in f32, t = (double)(1-u), trailing polynomial in f32 */
+#ifdef TCGPU_SPH_CUBIC_SPLINE
+                const double dwk = (double)tc_dm4((float)r, hq);           /* src/sph.c:374-378 */
+#else
                 const float u = tc_fdiv_apply(fd, (float)r);
                 const double t = (double)(1 - u);
                 const double t2 = t * t, t4 = t2 * t2, t7 = t4 * t2 * t;
                 const float polyf = __builtin_fmaf(u, __builtin_fmaf(u, 16.0f, 7.0f), 1.0f);
                 const double dwk = (double)(float)(norm_h4 * t7 * (double)u * (double)polyf);
+#endif
                 const double weight = wfac * dwk * rinv;
                 if (AW) {
                     const double wdA = weight * (ax - (double)pj.w);         /* dAx = dAy = dAz */

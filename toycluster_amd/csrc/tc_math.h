@@ -22,7 +22,11 @@
 #define TC_HD static inline
 #endif
 
+#ifdef TCGPU_SPH_CUBIC_SPLINE       /* the reference's -DSPH_CUBIC_SPLINE build, globals.h:40-52 */
+#define TC_DESNNGB 50               /* globals.h:42 */
+#else
 #define TC_DESNNGB 295              /* globals.h:48 */
+#endif
 #define TC_NNGBDEV 0.05             /* globals.h:49 */
 #define TC_NGBMAX (TC_DESNNGB * 8)  /* globals.h:50 */
 #define TC_NUMITER 64               /* wvt_relax.c:7 */
@@ -190,6 +194,26 @@ TC_HD int tc_common_levels(uint64_t ahi, uint64_t alo, uint64_t bhi, uint64_t bl
 /* sph.c:426-432: Wendland C6 with 1/h^3; args are f32, u=r/h is an f32 divide,
  * the polynomial runs in f64 left to right, the result is rounded to f32.
  * `norm_h3` must be  TC_WC6_NORM / (double)(h*h*h)  with h*h*h evaluated in f32. */
+/* sph.c:442-466: the cubic spline of the -DSPH_CUBIC_SPLINE build, statement for statement (u = r/h is an f32
+ * quotient promoted to double; the result is rounded to f32) */
+TC_HD float tc_m4(float r, float h)
+{
+    double wk = 0;
+    const double u = r / h;
+    if (u < 0.5) wk = (2.546479089470 + 15.278874536822 * (u - 1) * u * u);
+    else wk = 5.092958178941 * (1.0 - u) * (1.0 - u) * (1.0 - u);
+    return (float)(wk / (double)(h * h * h));
+}
+
+TC_HD float tc_dm4(float r, float h)
+{
+    double dwk = 0;
+    const double u = r / h;
+    if (u < 0.5) dwk = u * (45.836623610466 * u - 30.557749073644);
+    else dwk = (-15.278874536822) * (1.0 - u) * (1.0 - u);
+    return (float)(dwk / (double)(h * h * h * h));
+}
+
 TC_HD float tc_wc6(float r, float h, double norm_h3)
 {
     const double u = r / h;
