@@ -963,10 +963,11 @@ __device__ __forceinline__ void density_store(const tc_density_args &a, int i, c
 {
     if (lane_id() != 0) return;
     if (!d.ok) atomicOr(&a.flags[2], 1);
-    float varHsmlFac = (float)(1.0 / (double)(1 + d.hsml / (3 * d.rho) * d.dRhodHsml));
     a.hsml_out[i] = d.hsml;
     a.rho_out[i] = d.rho;
-    a.vhf_out[i] = varHsmlFac;
+    /* dRhodHsml; varHsmlFac = 1 / (1 + hsml / (3 rho) dRhodHsml) (src/sph.c:66) is formed by the kernel that scatters
+     * the results to the global arrays, one lane per particle, instead of by a whole wavefront here */
+    a.vhf_out[i] = d.dRhodHsml;
     if (STATS && a.stats) {
         a.stats[i] = d.nq;
         a.stats[i + (size_t)a.stats_stride] = d.nit;
@@ -1498,7 +1499,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
 
         if (!overflow) {
             if (do_wvt && cw < TC_NGBMAX) {
-                u0 = wsum(u0); u1 = wsum(u1); u2 = wsum(u2);
+                wsum2(u0, u1, u0, u1); u2 = wsum(u2);
                 wvt_done = true;
             }
             /* src/sph.c:36-64 on the two virtual queries */

@@ -710,9 +710,10 @@ __global__ __launch_bounds__(TB) void k_scatter_results(int nown, const uint32_t
     if (t >= nown) return;
     const uint32_t i = own ? own[t] : (uint32_t)t;
     const uint32_t g = lg[i];
-    ghsml[g] = hsml[i];
-    grho[g] = rho[i];
-    gvhf[g] = vhf[i];
+    const float h = hsml[i], r = rho[i], drho = vhf[i];      /* the solver kernels leave dRhodHsml in the vhf slot */
+    ghsml[g] = h;
+    grho[g] = r;
+    gvhf[g] = (float)(1.0 / (double)(1 + h / (3 * r) * drho));   /* src/sph.c:66 */
 }
 
 int tc_launch_scatter_results(tcgpu_ctx *c)
