@@ -21,7 +21,7 @@
 
 static const char *PHASE_NAMES[PH_COUNT] = {"peano_keys", "radix_sort", "permute", "cell_index", "hsml_guess",
                                             "density", "error_sums", "model_hsml", "wvt_sweep", "move",
-                                            "curl", "comm", "mirror", "local_set", "presentation"};
+                                            "curl", "comm", "mirror", "local_set", "presentation", "query_records"};
 
 struct rccl_api {
     void *h;
@@ -168,7 +168,7 @@ static void free_particles(tcgpu_ctx *c)
     TC_FREE(c->apot); TC_FREE(c->bfld); TC_FREE(c->l_apot);
     TC_FREE(c->key); TC_FREE(c->key_sorted); TC_FREE(c->idx); TC_FREE(c->idx_sorted); TC_FREE(c->sort_tmp);
     TC_FREE(c->cells); TC_FREE(c->guess); TC_FREE(c->hwvt); TC_FREE(c->delta); TC_FREE(c->stats); TC_FREE(c->ngb_buf);
-    TC_FREE(c->ustep); TC_FREE(c->rhom_next);
+    TC_FREE(c->ustep); TC_FREE(c->rhom_next); TC_FREE(c->prec);
     TC_FREE(c->cum); TC_FREE(c->scan_tmp); TC_FREE(c->mirror); TC_FREE(c->mirror_idx);
     c->cum_alloc = c->mirror_alloc = 0; c->mirror_valid = 0;
     c->cap = 0; c->n = 0; c->nloc = 0; c->nown = 0; c->ncells_alloc = 0;

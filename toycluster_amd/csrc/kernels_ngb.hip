@@ -265,6 +265,9 @@ __device__ __forceinline__ int query_level(const tc_dev_const &k, float h)
 /* The constants as ONE particle's queries see them: on a sharded pass every query of the particle is held to the
  * table levels the marking kernel sized the boxes for (tc_particle_levels; h0 = the carried smoothing length the pass
  * started from, w = the WVT hsml), on a full set to the whole table. */
+/* UNIFORM: the arguments are wave-uniform (one particle per wavefront) and the results are pinned to scalar registers;
+ * otherwise every lane works on a particle of its own (k_prec) */
+template <bool UNIFORM = true>
 __device__ __forceinline__ tc_dev_const particle_view(const tc_dev_const &k, float h0, float w)
 {
     tc_dev_const kk = k;
@@ -272,8 +275,8 @@ __device__ __forceinline__ tc_dev_const particle_view(const tc_dev_const &k, flo
         const float rg = tc_margin_radius(h0, w, k.boxsize, k.margin_widen);
         int la, lb;
         tc_particle_levels(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmax, h0, rg, &la, &lb);
-        kk.lmin_tab = U(la);
-        kk.lmax = U(lb);
+        kk.lmin_tab = UNIFORM ? U(la) : la;
+        kk.lmax = UNIFORM ? U(lb) : lb;
     }
     return kk;
 }
@@ -283,8 +286,10 @@ __device__ __forceinline__ double query_cell_edge_at(const tc_dev_const &k, int 
     return __builtin_ldexp(k.boxsize, -L);                                 /* box / 2^L, exact */
 }
 
+template <bool UNIFORM = true>
 __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, float yi, float zi, float h, tc_query &q)
 {
+#define UU(v) (UNIFORM ? U(v) : (v))
     const int L = query_level(k, h);
     q.L = L;
     q.nL = 1 << L;
@@ -292,9 +297,10 @@ __device__ __forceinline__ void query_setup(const tc_dev_const &k, float xi, flo
     const double inv_s = (double)q.nL * k.boxinv;
     /* layout of the level's box (wave-uniform: scalar loads) */
     const tc_level_desc D = k.lvl[L];
-    q.off = U(D.off);
-    q.ox = U(D.ox); q.oy = U(D.oy); q.oz = U(D.oz); q.ny = U(D.ny); q.nz = U(D.nz);
-    const int bo[3] = {q.ox, q.oy, q.oz}, bn[3] = {U(D.nx), q.ny, q.nz};
+    q.off = UU(D.off);
+    q.ox = UU(D.ox); q.oy = UU(D.oy); q.oz = UU(D.oz); q.ny = UU(D.ny); q.nz = UU(D.nz);
+    const int bo[3] = {q.ox, q.oy, q.oz}, bn[3] = {UU(D.nx), q.ny, q.nz};
+#undef UU
     /* pad: the f32 predicate can accept pairs a few ulp beyond h, and the per-cell culling below
      * runs in f32 on coordinates of magnitude boxsize (absolute error < 3e-7 boxsize) */
     const double hp = (double)h * (1.0 + 1e-5) + k.boxsize * 2e-6;
@@ -447,12 +453,24 @@ __device__ __forceinline__ bool consume_candidates(const tc_dev_const &k, const 
  * `idx` is this wave's LDS index list (TC_IDXCAP entries).  Returns the number of candidates.
  */
 template <class Body>
+__device__ __forceinline__ uint32_t stream_candidates_q(const tc_dev_const &k, const tc_query &q, float xi, float yi, float zi,
+                                                        uint32_t *idx, uint32_t idxcap, Body &&body);
+
+template <class Body>
 __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, float xi, float yi, float zi, float h,
                                                       uint32_t *idx, uint32_t idxcap, Body &&body)
 {
-    const int lane = lane_id();
     tc_query q;
     query_setup(k, xi, yi, zi, h, q);
+    return stream_candidates_q(k, q, xi, yi, zi, idx, idxcap, body);
+}
+
+/* ... with the query geometry already worked out (k_prec) */
+template <class Body>
+__device__ __forceinline__ uint32_t stream_candidates_q(const tc_dev_const &k, const tc_query &q, float xi, float yi, float zi,
+                                                        uint32_t *idx, uint32_t idxcap, Body &&body)
+{
+    const int lane = lane_id();
     int norph = *k.norph;
     if (norph > TC_MAX_ORPHANS) norph = TC_MAX_ORPHANS;   /* overflow is flagged by k_cells */
     uint32_t ncand = 0;
@@ -567,13 +585,24 @@ __device__ __forceinline__ uint32_t stream_candidates(const tc_dev_const &k, flo
  * per-lane loops.  body(slot, p, active) as in stream_candidates, but `slot` indexes the mirror.
  */
 template <bool XYZ_ONLY = false, class Body>
+__device__ __forceinline__ uint32_t stream_rows_q(const tc_dev_const &k, const tc_query &q, float xi, float yi, float zi,
+                                                  uint32_t *heads, Body &&body TC_PROF_PARAM);
+
+template <bool XYZ_ONLY = false, class Body>
 __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi, float yi, float zi, float h,
                                                 uint32_t *heads, Body &&body TC_PROF_PARAM)
 {
-    const int lane = lane_id();
     tc_query q;
-    TC_STAGE_SWITCH(ST_PROLOGUE, ST_PRODUCER);
     query_setup(k, xi, yi, zi, h, q);
+    return stream_rows_q<XYZ_ONLY>(k, q, xi, yi, zi, heads, body TC_PROF_PASS);
+}
+
+template <bool XYZ_ONLY, class Body>
+__device__ __forceinline__ uint32_t stream_rows_q(const tc_dev_const &k, const tc_query &q, float xi, float yi, float zi,
+                                                  uint32_t *heads, Body &&body TC_PROF_PARAM)
+{
+    const int lane = lane_id();
+    TC_STAGE_SWITCH(ST_PROLOGUE, ST_PRODUCER);
     const uint32_t *cum = k.cum;                      /* indexed with table entries (rowlin carries the level's offset) */
     const tc_gpos mirror = vgpr_pos(k.mirror);
     const uint32_t padslot = vgpr_u32(k.mirror_pad);
@@ -1276,10 +1305,72 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
  * The sweep is accumulated for unit step: the step size is decided by the host from this very
  * pass's error sums (src/wvt_relax.c:89-101); k_move applies delta = step * U.
  */
+/* What a wavefront needs to know about its particle before it can stream candidates -- the three radii, the table
+ * level, the cell box of the query -- is ~150 instructions of mostly f64 arithmetic on wave-uniform values: executed
+ * by 64 lanes for one particle it is as expensive as 150 instructions of the neighbour loops.  k_prec works it out
+ * for 64 particles per wavefront instead (one lane each, the same functions) and leaves a 64-byte record that the
+ * fused kernel reads with scalar loads. */
+struct tc_prec {
+    float h0, hb, hw, R;              /* carried hsml, 1.23 hsml, sweep radius, gather radius */
+    float h0sq, hbsq, hwsq, smax;
+    float sf, hpf, inv_ny, inv_sf;    /* tc_query */
+    int lo[3];
+    uint32_t pack;                    /* qL : 4 | flags : 7 | nd[0..2] : 7 each */
+};
+#define TC_PREC_WARM 1u
+#define TC_PREC_WRAP 2u
+#define TC_PREC_FAST 4u
+#define TC_PREC_FULL0 8u              /* FULL0 << d: dimension d covers the whole ring (nd = 2^qL) */
+#define TC_PREC_VALID 64u             /* the record describes the query (else: work it out in the kernel) */
+
 struct tc_iter_args {
     tc_density_args d;
     double *ustep;             /* 3n, unit-step displacement sums; NULL => density only */
+    const tc_prec *prec;       /* one record per local slot of an own particle */
 };
+
+__global__ __launch_bounds__(256) void k_prec(tc_dev_const k0, const float *__restrict__ hsml_in, int do_wvt,
+                                              tc_prec *__restrict__ prec)
+{
+    const int t = k0.lo + blockIdx.x * 256 + threadIdx.x;
+    if (t >= k0.hi) return;
+    const int i = k0.own ? (int)k0.own[t] : t;
+    const float4 pv = k0.pos4[i];
+    const float h0 = hsml_in[i];
+    tc_prec P;
+    P.pack = 0;
+    P.h0 = h0;
+    P.hb = (float)((double)h0 * 1.23);
+    P.hw = (float)((double)pv.w * k0.boxsize);                      /* src/wvt_relax.c:135 */
+    P.h0sq = P.h0 * P.h0; P.hbsq = P.hb * P.hb; P.hwsq = P.hw * P.hw;
+    P.R = (do_wvt && P.hw > P.hb) ? P.hw : P.hb;
+    P.smax = (P.hwsq > P.hbsq && do_wvt) ? P.hwsq : P.hbsq;
+    P.sf = P.hpf = P.inv_ny = P.inv_sf = 0;
+    P.lo[0] = P.lo[1] = P.lo[2] = 0;
+    if (isfinite(h0) && h0 != 0) {
+        const tc_dev_const k = particle_view<false>(k0, h0, pv.w);
+        tc_query q;
+        query_setup<false>(k, pv.x, pv.y, pv.z, P.R, q);
+        const int qL = q.L;
+        const double ext = (double)P.R * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge_at(k, qL);
+        const bool wrap = !((double)pv.x >= ext && (double)pv.x <= k.boxsize - ext && (double)pv.y >= ext
+                            && (double)pv.y <= k.boxsize - ext && (double)pv.z >= ext && (double)pv.z <= k.boxsize - ext);
+        const bool fast = !wrap && k.mirror != nullptr && qL <= k.lmax_rm && qL >= k.lmin_rm;
+        uint32_t fl = TC_PREC_WARM | (wrap ? TC_PREC_WRAP : 0u) | (fast ? TC_PREC_FAST : 0u);
+        bool fits = qL < 16;
+        uint32_t nds = 0;
+        for (int d = 0; d < 3; d++) {
+            if (q.full[d]) fl |= TC_PREC_FULL0 << d;
+            else if (q.nd[d] > 127) fits = false;
+            else nds |= (uint32_t)q.nd[d] << (7 * d);
+            P.lo[d] = q.lo[d];
+        }
+        if (fits) fl |= TC_PREC_VALID;
+        P.sf = q.sf; P.hpf = q.hpf; P.inv_ny = q.inv_ny; P.inv_sf = q.inv_sf;
+        P.pack = (uint32_t)qL | (fl << 4) | (nds << 11);
+    }
+    prec[i] = P;
+}
 
 /* Sized for 4 waves per SIMD (<= 128 VGPRs, 4 blocks x 38.9 KB LDS per CU): measured 4 % faster than 3 waves
  * with 512/384/512 (tools/try_libs.sh, same box).  Longer lists continue in the per-wave global spill.
@@ -1311,7 +1402,11 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     const int lane = lane_id();
     /* the particle's own data is wave-uniform: keep it in scalar registers */
     const float4 pv = da.k.pos4[i];
-    const tc_dev_const k = particle_view(da.k, da.hsml_in[i], pv.w);
+    const tc_prec P = a.prec[i];                       /* scalar loads: the wave-uniform prologue was done by k_prec */
+    const uint32_t pflags = U(P.pack >> 4) & 0x7fu;
+    const bool have_prec = (pflags & TC_PREC_VALID) != 0;
+    /* the per-particle view of the constants (level range of a sharded pass) is only needed off the common path */
+    const tc_dev_const &k = da.k;
     const float4 pi = make_float4(U(pv.x), U(pv.y), U(pv.z), U(pv.w));
     const float xi = pi.x, yi = pi.y, zi = pi.z;
     constexpr bool do_wvt = WVT;                       /* a.ustep != nullptr */
@@ -1339,25 +1434,31 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     double u0 = 0, u1 = 0, u2 = 0;
     bool wvt_done = false;
 
-    if (warm) {
-        const float h0 = U(d.hsml);
-        const float hb = U((float)((double)h0 * 1.23));
-        const float h0sq = U(h0 * h0), hbsq = U(hb * hb);
-        const float hw = U((float)((double)pi.w * k.boxsize));       /* src/wvt_relax.c:135 */
-        const float hwsq = U(hw * hw);
-        const float R = (do_wvt && hw > hb) ? hw : hb;
+    if (warm && have_prec) {
+        const float hb = U(P.hb), h0sq = U(P.h0sq), hbsq = U(P.hbsq), hwsq = U(P.hwsq);
         const double boxinv = k.boxinv;
         const double step_hi = (double)pi.w;                          /* unit step */
-        /* every candidate lies in a cell overlapping [x-R', x+R'], i.e. within R' + s of x per coordinate */
-        const int qL = query_level(k, R);
-        const double ext = (double)R * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge_at(k, qL);
-        const bool wrap = U((int)!((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
-                                   && (double)yi <= k.boxsize - ext && (double)zi >= ext
-                                   && (double)zi <= k.boxsize - ext)) != 0;
-        /* interior ball at a mirrored level: candidates come as contiguous runs of the row-major mirror
-         * (stream_rows); `j` is then a mirror slot.  No orphan (coordinate == boxsize) can be within R of an
-         * interior particle, so skipping them there changes nothing. */
-        const bool fast = U((int)(!wrap && k.mirror != nullptr && qL <= k.lmax_rm && qL >= k.lmin_rm)) != 0;
+        /* wrap: some candidate may lie beyond box/2 in a coordinate; fast: interior ball at a mirrored level --
+         * candidates come as contiguous runs of the row-major mirror (stream_rows), `j` is then a mirror slot.  No
+         * orphan (coordinate == boxsize) can be within R of an interior particle, so skipping them there changes nothing. */
+        const bool wrap = (pflags & TC_PREC_WRAP) != 0;
+        const bool fast = (pflags & TC_PREC_FAST) != 0;
+        tc_query q;
+        {
+            const uint32_t pk = U(P.pack);
+            q.L = (int)(pk & 15u);
+            q.nL = 1 << q.L;
+            const tc_level_desc D = k.lvl[q.L];
+            q.off = U(D.off);
+            q.ox = U(D.ox); q.oy = U(D.oy); q.oz = U(D.oz); q.ny = U(D.ny); q.nz = U(D.nz);
+#pragma unroll
+            for (int dd = 0; dd < 3; dd++) {
+                q.full[dd] = (pflags & (TC_PREC_FULL0 << dd)) != 0;
+                q.nd[dd] = q.full[dd] ? q.nL : (int)((pk >> (11 + 7 * dd)) & 127u);
+                q.lo[dd] = U(P.lo[dd]);
+            }
+            q.sf = U(P.sf); q.hpf = U(P.hpf); q.inv_ny = U(P.inv_ny); q.inv_sf = U(P.inv_sf);
+        }
         /* the gather below is compiled twice (tag F): on the row-run path nothing wraps, positions come
          * from the mirror and "self" is the slot whose Peano index is i -- all compile-time there */
 
@@ -1372,7 +1473,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
          * 1.23 hsml for the density ball), so candidates are tested ONCE against the larger of the two squares and
          * staged in one ring; which lists a staged hit belongs to is decided 64 hits at a time in convert_d, on
          * full waves, from the f32 r2 staged with it -- the reference's predicates exactly (src/tree.c:67-89). */
-        float smax = U(hwsq > hbsq && do_wvt ? hwsq : hbsq);
+        float smax = P.smax;
         asm volatile("v_mov_b32 %0, %0" : "+v"(smax));          /* parked in a VGPR: the scalar file is full (a spilled
                                                                  * SGPR costs a v_readlane per candidate batch) */
         bool stopped = false;
@@ -1473,8 +1574,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         bool overflow;
         if (fast) {
             const std::true_type F;
-            d.ncand += stream_rows<true>(k, xi, yi, zi, R, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); }
-                                   TC_PROF_PASS);
+            d.ncand += stream_rows_q<true>(k, q, xi, yi, zi, idx,
+                                           [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); } TC_PROF_PASS);
             overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
             TC_STAGE_SWITCH(ST_EPILOGUE, ST_TEST);
             if (!overflow) {
@@ -1486,8 +1587,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             TC_STAGE_SWITCH(ST_TEST, ST_EPILOGUE);
         } else {
             const std::false_type F;
-            d.ncand += stream_candidates(k, xi, yi, zi, R, idx, idxcap,
-                                         [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
+            d.ncand += stream_candidates_q(k, q, xi, yi, zi, idx, idxcap,
+                                           [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
             overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
             if (!overflow) {
                 if (dcnt > 0) { pad_stage((uint32_t)i, dcnt); convert_d(F); }
@@ -1533,12 +1634,16 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
 
     if (finite && !d.ok && isfinite(d.hsml)) {
         const float rmax = k.margin_on ? tc_margin_radius(da.hsml_in[i], pi.w, k.boxsize, k.margin_widen) : HUGE_VALF;
-        density_loop(da, k, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d, rmax);
+        const tc_dev_const kv = particle_view(da.k, da.hsml_in[i], pi.w);
+        density_loop(da, kv, i, xi, yi, zi, plain, idx, TC_ITER_IDXCAP, st, d, rmax);
     }
     if (finite) density_store<STATS>(da, i, d);
 
     if (do_wvt) {
-        if (!wvt_done) wvt_sum(k, i, pi, (double)pi.w, da.flags, idx, TC_ITER_IDXCAP, sw, u0, u1, u2);
+        if (!wvt_done) {
+            const tc_dev_const kv = particle_view(da.k, da.hsml_in[i], pi.w);
+            wvt_sum(kv, i, pi, (double)pi.w, da.flags, idx, TC_ITER_IDXCAP, sw, u0, u1, u2);
+        }
         if (lane == 0) {
             a.ustep[3 * (size_t)i] = u0;
             a.ustep[3 * (size_t)i + 1] = u1;
@@ -1605,6 +1710,11 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     int nloc = a.d.k.hi - a.d.k.lo;
     if (nloc <= 0) return 0;
+    if (!c->prec) TC_HIP(c, hipMalloc(&c->prec, (size_t)c->cap * sizeof(tc_prec)));
+    a.prec = (const tc_prec *)c->prec;
+    tc_phase_begin(c, PH_PREC);
+    k_prec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a.d.k, a.d.hsml_in, with_wvt, (tc_prec *)c->prec);
+    tc_phase_end(c);
     tc_phase_begin(c, PH_DENSITY);
 #define TC_LAUNCH_ITER(S, W) k_iter<S, W><<<grid_for(c, nloc, k_iter<S, W>), TBN, 0, c->stream>>>(a)
     if (a.d.stats) { if (with_wvt) TC_LAUNCH_ITER(true, true); else TC_LAUNCH_ITER(true, false); }

@@ -22,7 +22,7 @@
 
 enum tc_phase {
     PH_KEYS = 0, PH_SORT, PH_PERMUTE, PH_CELLS, PH_GUESS, PH_DENSITY, PH_ERROR, PH_MODEL_HSML,
-    PH_WVT, PH_MOVE, PH_CURL, PH_COMM, PH_MIRROR, PH_LOCAL, PH_PRESENT, PH_COUNT
+    PH_WVT, PH_MOVE, PH_CURL, PH_COMM, PH_MIRROR, PH_LOCAL, PH_PRESENT, PH_PREC, PH_COUNT
 };
 
 /* One level of the cell table: the dense (x, y, z) array, z fastest, of the cells [o, o + n) per dimension -- the
@@ -202,6 +202,7 @@ struct tcgpu_ctx {
     size_t ncells_alloc;
     double *spill;                /* TC_MAX_PERSISTENT_BLOCKS*WPB x 2*NGBMAX */
     double *ustep;                /* 3*cap: unit-step WVT displacement sums of the fused kernel (local order) */
+    void *prec;                   /* cap x 64 B: per-particle query records of the fused kernel (k_prec), on demand */
     float *rhom_next;             /* cap: model density at the current positions, committed by the sweep (G order) */
     int ustep_valid;              /* ustep belongs to the current local order and positions */
     int fuse;                     /* option: use the fused kernel (default 1) */
