@@ -226,8 +226,9 @@ def main():
                                    "WVT iterations (sort + density solve + sweep + move)" % args.particles_per_gpu,
                        "particles_total": n_total, "priming": "2 untimed iterations before the warm-up (cold start from hsml = 0)",
                        "parallelism": "peano-range shards x%d: per-rank local set (own range + ghost shell) with its own "
-                                      "sort / cell table / mirror; one RCCL all-gather of positions (16 B/particle) and two "
-                                      "exact scalar all-reduces per iteration" % world,
+                                      "sort / cell table / mirror; per iteration the ghost exchange over RCCL (interest pyramids "
+                                      "all-gathered, 20 B per ghost sent to the ranks that need it) and two exact scalar "
+                                      "all-reduces" % world,
                        "rank0_local_set": lset, "rank0_recv_bytes_per_step": recv_bytes,
                        "err_mean_last": errs[-1][0], "err_max_last": errs[-1][1]},
             # k_iter is a gather/stencil kernel bound by the vector ALU, not by HBM: the
