@@ -1736,7 +1736,19 @@ struct tc_curl_args {
     int *ovf_count;
     int ovf_cap;
     int *flags;
+    const struct tc_cprec *prec;   /* per-particle records of k_curl (k_cprec); shares the fused kernel's record buffer */
 };
+
+/* the wave-uniform prologue of curl_one, one lane per particle (see tc_prec): 64 bytes */
+struct tc_cprec {
+    double norm_h4, wfac;             /* WC6' normalisation (src/sph.c:439), -m / rho_i * varHsmlFac (src/sph.c:282) */
+    float hq, hq2, fdy;               /* smoothing length, its square, 1 / hq of the f32 quotient (tc_fdiv) */
+    float sf, hpf, inv_ny, inv_sf;    /* tc_query */
+    int lo[3];
+    uint32_t pack;                    /* qL : 4 | flags : 7 | nd[0..2] : 7 each; flag bit 0 = exact division here */
+    uint32_t pad;
+};
+static_assert(sizeof(tc_cprec) == sizeof(tc_prec), "both records live in the same 64-byte slots");
 
 /* src/sph.c:224-295 for particle i, pair by pair under the candidate predicate: the fall-back for a ball that
  * overflows NGBMAX (the reference then truncates its list, src/tree.c:91-92) */
@@ -1818,28 +1830,89 @@ __device__ __forceinline__ void curl_one_slow(const tc_curl_args &a, int i, uint
  * the row-major mirror where the ball is interior (stream_rows) or cell by cell, the f32 predicate of the
  * reference's ball query (src/tree.c:67-89) picks the hits, hits are compacted into an LDS ring of indices, and
  * the f64 pair term -- separation, W', Price (2010) eq. 79 -- is evaluated 64 hits at a time on full waves. */
+/* one lane per particle: everything curl_one needs to know about its particle before it streams candidates */
+__global__ __launch_bounds__(256) void k_cprec(tc_curl_args a, tc_cprec *__restrict__ prec)
+{
+    const tc_dev_const &k0 = a.k;
+    const int t = k0.lo + blockIdx.x * 256 + threadIdx.x;
+    if (t >= k0.hi) return;
+    const int i = k0.own ? (int)k0.own[t] : t;
+    const float4 pv = k0.pos4[i];
+    const float hq = a.hsml[i];
+    const tc_dev_const k = particle_view<false>(k0, hq, 0.0f);   /* the curl's local set is marked from hsml alone (api.hip) */
+    tc_cprec P;
+    P.hq = hq;
+    P.hq2 = hq * hq;
+    P.norm_h4 = TC_WC6_NORM / (double)(hq * hq * hq * hq) * -22.0;
+    P.wfac = -k.mpart / (double)a.rho[i] * (double)a.vhf[i];
+    const tc_fdiv fd = tc_fdiv_setup(hq);
+    P.fdy = fd.y;
+    tc_query q;
+    query_setup<false>(k, pv.x, pv.y, pv.z, hq, q);
+    const int qL = q.L;
+    const double ext = (double)hq * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge_at(k, qL);
+    const bool wrap = !((double)pv.x >= ext && (double)pv.x <= k.boxsize - ext && (double)pv.y >= ext
+                        && (double)pv.y <= k.boxsize - ext && (double)pv.z >= ext && (double)pv.z <= k.boxsize - ext);
+    const bool fast = !wrap && k.mirror != nullptr && qL <= k.lmax_rm && qL >= k.lmin_rm;
+    uint32_t fl = (fd.exact_div ? TC_PREC_WARM : 0u) | (wrap ? TC_PREC_WRAP : 0u) | (fast ? TC_PREC_FAST : 0u);
+    bool fits = qL < 16 && isfinite(hq);
+    uint32_t nds = 0;
+    for (int d = 0; d < 3; d++) {
+        if (q.full[d]) fl |= TC_PREC_FULL0 << d;
+        else if (q.nd[d] > 127) fits = false;
+        else nds |= (uint32_t)q.nd[d] << (7 * d);
+        P.lo[d] = q.lo[d];
+    }
+    if (fits) fl |= TC_PREC_VALID;
+    P.sf = q.sf; P.hpf = q.hpf; P.inv_ny = q.inv_ny; P.inv_sf = q.inv_sf;
+    P.pack = (uint32_t)qL | (fl << 4) | (nds << 11);
+    P.pad = 0;
+    prec[i] = P;
+}
+
 template <bool AW>     /* AW: the three components of A are equal and ride in the w lane of the positions (magnetic_field.c:63-65) */
 __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t *idx, uint32_t *ring, const tc_stage &st)
 {
     const int lane = lane_id();
     const float4 pv = a.k.pos4[i];
     const float xi = U(pv.x), yi = U(pv.y), zi = U(pv.z);
-    const float hq = U(a.hsml[i]);
-    const tc_dev_const k = particle_view(a.k, hq, 0.0f);      /* the curl's local set is marked from hsml alone (api.hip) */
-    const float hq2 = hq * hq;
-    const double hsml = hq, rho_i = a.rho[i], vhf = a.vhf[i];
+    const tc_dev_const &k = a.k;
+    const tc_cprec P = a.prec[i];                             /* scalar loads (k_cprec) */
+    const uint32_t pk = U(P.pack);
+    const uint32_t pflags = (pk >> 4) & 0x7fu;
+    if (!(pflags & TC_PREC_VALID)) {                          /* a query the record cannot describe: the literal path */
+        if (lane == 0) {
+            const int slot = atomicAdd(a.ovf_count, 1);
+            if (slot < a.ovf_cap) a.ovf_list[slot] = (uint32_t)i;
+            else atomicOr(&a.flags[3], 1);
+        }
+        return;
+    }
+    const float hq = U(P.hq), hq2 = U(P.hq2);
+    const double hsml = hq;
     const double ax = a.apot[3 * (size_t)i], ay = a.apot[3 * (size_t)i + 1], az = a.apot[3 * (size_t)i + 2];
-    const double norm_h4 = TC_WC6_NORM / (double)(hq * hq * hq * hq) * -22.0;
+    const double norm_h4 = P.norm_h4;
     (void)norm_h4;                                           /* the cubic-spline build has its own normalisation */
-    const double wfac = -k.mpart / rho_i * vhf;             /* -m/rho_i * varHsmlFac (src/sph.c:282), dwk/r per pair */
-    tc_fdiv fd = tc_fdiv_setup(hq);
-    fd.exact_div = U(fd.exact_div);
-
-    const int qL = query_level(k, hq);
-    const double ext = (double)hq * (1.0 + 1e-5) + k.boxsize * 1.2e-5 + query_cell_edge_at(k, qL);
-    const bool wrap = U((int)!((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
-                               && (double)yi <= k.boxsize - ext && (double)zi >= ext && (double)zi <= k.boxsize - ext)) != 0;
-    const bool fast = U((int)(!wrap && k.mirror != nullptr && qL <= k.lmax_rm && qL >= k.lmin_rm)) != 0;
+    const double wfac = P.wfac;                              /* -m/rho_i * varHsmlFac (src/sph.c:282), dwk/r per pair */
+    tc_fdiv fd;
+    fd.b = hq; fd.y = U(P.fdy); fd.exact_div = (pflags & TC_PREC_WARM) != 0;
+    const bool wrap = (pflags & TC_PREC_WRAP) != 0;
+    const bool fast = (pflags & TC_PREC_FAST) != 0;
+    tc_query q;
+    {
+        q.L = (int)(pk & 15u);
+        q.nL = 1 << q.L;
+        const tc_level_desc D = k.lvl[q.L];
+        q.off = U(D.off);
+        q.ox = U(D.ox); q.oy = U(D.oy); q.oz = U(D.oz); q.ny = U(D.ny); q.nz = U(D.nz);
+#pragma unroll
+        for (int dd = 0; dd < 3; dd++) {
+            q.full[dd] = (pflags & (TC_PREC_FULL0 << dd)) != 0;
+            q.nd[dd] = q.full[dd] ? q.nL : (int)((pk >> (11 + 7 * dd)) & 127u);
+            q.lo[dd] = U(P.lo[dd]);
+        }
+        q.sf = U(P.sf); q.hpf = U(P.hpf); q.inv_ny = U(P.inv_ny); q.inv_sf = U(P.inv_sf);
+    }
     const tc_gpos vmirror = vgpr_pos(k.mirror);
 
     double b0 = 0, b1 = 0, b2 = 0;
@@ -1930,11 +2003,11 @@ __device__ __forceinline__ void curl_one(const tc_curl_args &a, int i, uint32_t 
     };
     if (fast) {
         const std::true_type F;
-        stream_rows(k, xi, yi, zi, hq, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
+        stream_rows_q<false>(k, q, xi, yi, zi, idx, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
         if (cnt < TC_NGBMAX && scnt > 0) convert(F, scnt);
     } else {
         const std::false_type F;
-        stream_candidates(k, xi, yi, zi, hq, idx, TC_IDXCAP, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
+        stream_candidates_q(k, q, xi, yi, zi, idx, TC_IDXCAP, [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); });
         if (cnt < TC_NGBMAX && scnt > 0) convert(F, scnt);
     }
     if (cnt >= TC_NGBMAX) {                                    /* list truncation semantics: left to k_curl_slow */
@@ -1993,9 +2066,12 @@ int tc_launch_curl(tcgpu_ctx *c, float *l_bfld, int a_in_w)
     a.flags = c->flags;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
+    if (!c->prec) TC_HIP(c, hipMalloc(&c->prec, (size_t)c->cap * sizeof(tc_cprec)));
+    a.prec = (const tc_cprec *)c->prec;
     tc_phase_begin(c, PH_CURL);
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     TC_HIP(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(int), c->stream));
+    if (!c->curl_literal) k_cprec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a, (tc_cprec *)c->prec);
     if (c->curl_literal) {                       /* option "curl_literal" (tests): every particle through the literal path */
         const int cnt = nloc;
         if (c->nranks > 1) TC_HIP(c, hipMemcpyAsync(a.ovf_list, c->own_list, (size_t)nloc * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
