@@ -174,6 +174,8 @@ int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
  *   "lmax" [auto]     deepest cell-table level (set before upload)
  *   "force_comm" [0]  tests: run the RCCL calls with a 1-rank communicator
  *   "curl_literal" [0] tests: the curl's literal pair-by-pair path (the NGBMAX-overflow fall-back) for every particle
+ *   "no_records" [0]  tests: treat every per-particle query record as unusable (the plain per-query code / the curl's
+ *                     literal path then solve every particle)
  *   "ghost_exchange" [1] sharded contexts: 1 = a rank receives only its ghost particles whenever that moves fewer bytes
  *                     than every position to every rank, 2 = always, 0 = never (position all-gather); same results
  *   "blocks_per_cu" [0] profiling: cap on the co-resident blocks per CU of the persistent kernels (0 = all)

@@ -329,6 +329,36 @@ def test_cubic_spline_variant_vs_oracle():
         g.close()
 
 
+def test_unusable_query_records_fall_back(golden_case):
+    """k_prec / k_cprec hand the solver kernels a 64-byte record per particle; one that cannot describe its query (a cell
+    box wider than 127 cells -- never seen in practice) must send the particle down the plain per-query code, the curl
+    down its literal path.  Forced for every particle here: same relaxation log, same particles (to summation order),
+    same field as the default run."""
+    c = golden_case
+    out = []
+    for flag in (0, 1):
+        g = binding.TcGpu(0, options={"no_records": flag})
+        try:
+            g.set_model(c["model"])
+            g.upload(c["pos"], c["ids"])
+            log = g.Regularise_sph_particles(max_iter=2)
+            g.Find_sph_quantities()
+            p = g.particles()
+            a = (p["rho_model"] / p["rho_model"].max()) ** 0.5
+            b = g.Bfld_from_rotA_SPH(np.stack([a, a, a], axis=1).astype(np.float32))
+            out.append((log, p, b))
+        finally:
+            g.close()
+    (l0, p0, b0), (l1, p1, b1) = out
+    assert len(l0) == len(l1)
+    for x, y in zip(l0, l1):
+        assert x["err_mean"] == pytest.approx(y["err_mean"], rel=1e-6) and x["step"] == y["step"]
+    assert np.array_equal(p0["id"], p1["id"])
+    assert (np.abs(p0["pos"] - p1["pos"]).max(axis=1) / p0["hsml"]).max() < TOL_POS
+    assert np.median(rel(p1["hsml"], p0["hsml"])) < 1e-6 and rel(p1["rho"], p0["rho"]).max() < 1e-4
+    assert np.abs(b1 - b0).max() < 1e-5 * np.abs(b0).max()
+
+
 def test_density_pass_cold(gpu, golden_case):
     c = golden_case
     gpu.set_model(c["model"])

@@ -1389,6 +1389,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "blocks_per_cu")) c->blocks_per_cu = (int)value;   /* profiling: cap the persistent grid */
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
     else if (!strcmp(name, "curl_literal")) c->curl_literal = value != 0;
+    else if (!strcmp(name, "no_records")) c->no_records = value != 0;    /* tests: the fall-back of k_prec / k_cprec */
     else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = c->lmax_rm0 = 0; }
     else if (!strcmp(name, "force_comm")) c->force_comm = value != 0;   /* tests: 1-rank RCCL communicator */
     else if (!strcmp(name, "ghost_exchange")) c->ghost_mode = (int)value; /* 0: position all-gather every pass, 1: whichever is cheaper (default), 2: always ghosts */

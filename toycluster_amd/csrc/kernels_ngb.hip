@@ -1330,7 +1330,7 @@ struct tc_iter_args {
 };
 
 __global__ __launch_bounds__(256) void k_prec(tc_dev_const k0, const float *__restrict__ hsml_in, int do_wvt,
-                                              tc_prec *__restrict__ prec)
+                                              int no_records, tc_prec *__restrict__ prec)
 {
     const int t = k0.lo + blockIdx.x * 256 + threadIdx.x;
     if (t >= k0.hi) return;
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(256) void k_prec(tc_dev_const k0, const float *__re
             else nds |= (uint32_t)q.nd[d] << (7 * d);
             P.lo[d] = q.lo[d];
         }
-        if (fits) fl |= TC_PREC_VALID;
+        if (fits && !no_records) fl |= TC_PREC_VALID;      /* no_records (tests): every particle down the plain path */
         P.sf = q.sf; P.hpf = q.hpf; P.inv_ny = q.inv_ny; P.inv_sf = q.inv_sf;
         P.pack = (uint32_t)qL | (fl << 4) | (nds << 11);
     }
@@ -1713,7 +1713,7 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     if (!c->prec) TC_HIP(c, hipMalloc(&c->prec, (size_t)c->cap * sizeof(tc_prec)));
     a.prec = (const tc_prec *)c->prec;
     tc_phase_begin(c, PH_PREC);
-    k_prec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a.d.k, a.d.hsml_in, with_wvt, (tc_prec *)c->prec);
+    k_prec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a.d.k, a.d.hsml_in, with_wvt, c->no_records, (tc_prec *)c->prec);
     tc_phase_end(c);
     tc_phase_begin(c, PH_DENSITY);
 #define TC_LAUNCH_ITER(S, W) k_iter<S, W><<<grid_for(c, nloc, k_iter<S, W>), TBN, 0, c->stream>>>(a)
@@ -1831,7 +1831,7 @@ __device__ __forceinline__ void curl_one_slow(const tc_curl_args &a, int i, uint
  * reference's ball query (src/tree.c:67-89) picks the hits, hits are compacted into an LDS ring of indices, and
  * the f64 pair term -- separation, W', Price (2010) eq. 79 -- is evaluated 64 hits at a time on full waves. */
 /* one lane per particle: everything curl_one needs to know about its particle before it streams candidates */
-__global__ __launch_bounds__(256) void k_cprec(tc_curl_args a, tc_cprec *__restrict__ prec)
+__global__ __launch_bounds__(256) void k_cprec(tc_curl_args a, int no_records, tc_cprec *__restrict__ prec)
 {
     const tc_dev_const &k0 = a.k;
     const int t = k0.lo + blockIdx.x * 256 + threadIdx.x;
@@ -1863,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_cprec(tc_curl_args a, tc_cprec *__restr
         else nds |= (uint32_t)q.nd[d] << (7 * d);
         P.lo[d] = q.lo[d];
     }
-    if (fits) fl |= TC_PREC_VALID;
+    if (fits && !no_records) fl |= TC_PREC_VALID;
     P.sf = q.sf; P.hpf = q.hpf; P.inv_ny = q.inv_ny; P.inv_sf = q.inv_sf;
     P.pack = (uint32_t)qL | (fl << 4) | (nds << 11);
     P.pad = 0;
@@ -2071,7 +2071,7 @@ int tc_launch_curl(tcgpu_ctx *c, float *l_bfld, int a_in_w)
     tc_phase_begin(c, PH_CURL);
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     TC_HIP(c, hipMemsetAsync(c->d_count + 3, 0, sizeof(int), c->stream));
-    if (!c->curl_literal) k_cprec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a, (tc_cprec *)c->prec);
+    if (!c->curl_literal) k_cprec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a, c->no_records, (tc_cprec *)c->prec);
     if (c->curl_literal) {                       /* option "curl_literal" (tests): every particle through the literal path */
         const int cnt = nloc;
         if (c->nranks > 1) TC_HIP(c, hipMemcpyAsync(a.ovf_list, c->own_list, (size_t)nloc * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));

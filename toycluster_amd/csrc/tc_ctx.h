@@ -202,6 +202,7 @@ struct tcgpu_ctx {
     size_t ncells_alloc;
     double *spill;                /* TC_MAX_PERSISTENT_BLOCKS*WPB x 2*NGBMAX */
     double *ustep;                /* 3*cap: unit-step WVT displacement sums of the fused kernel (local order) */
+    int no_records;               /* option "no_records" (tests): mark every per-particle record unusable */
     void *prec;                   /* cap x 64 B: per-particle query records of the fused kernel (k_prec), on demand */
     float *rhom_next;             /* cap: model density at the current positions, committed by the sweep (G order) */
     int ustep_valid;              /* ustep belongs to the current local order and positions */
