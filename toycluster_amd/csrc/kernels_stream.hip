@@ -335,7 +335,7 @@ int tc_launch_mark_interest(tcgpu_ctx *c)
     TC_HIP(c, hipMemcpyAsync(c->lvl_range, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     if (hi > lo) {
         /* contiguous chunks of the own range, a multiple of the block size, 4 blocks per CU (measured best of 2 / 4 / 8 / 16: the per-block LDS set-up and flush against parallelism) */
-        int64_t nblocks = (int64_t)c->num_cu * (getenv("TCGPU_MARK_BPC") ? atoi(getenv("TCGPU_MARK_BPC")) : 4);
+        int64_t nblocks = (int64_t)c->num_cu * 4;
         int64_t chunk = ((hi - lo + nblocks - 1) / nblocks + TB - 1) / TB * TB;
         nblocks = (hi - lo + chunk - 1) / chunk;
         k_mark_interest<<<(unsigned)nblocks, TB, 0, c->stream>>>(
