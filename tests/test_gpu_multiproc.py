@@ -35,7 +35,9 @@ WORKER = textwrap.dedent('''
         uid = None
     m = M.preset("merger", n)
     pos, ids = M.sample_gas(m, n, seed=23)
-    g = binding.TcGpu(rank, rank=rank, nranks=world, unique_id=uid)
+    # ghost_exchange = 2: always the pyramids + grouped ncclSend / ncclRecv (at this size the automatic choice would
+    # be the position all-gather)
+    g = binding.TcGpu(rank, rank=rank, nranks=world, unique_id=uid, options={"ghost_exchange": 2})
     g.set_model(m)
     g.upload(pos, ids)
     log = g.Regularise_sph_particles(max_iter=4)
