@@ -733,11 +733,15 @@ struct tc_density_args {
 template <class F>
 __device__ __forceinline__ void scan_segment(const double *p, int n, double pad, F &&f)
 {
-    for (int kk = lane_id(); kk < n; kk += 128) {
-        const int k2 = kk + 64;
-        double ra = p[kk];
-        double rb = k2 < n ? p[k2] : pad;
-        f(ra, rb);
+    /* `two`: the trip really has a second half-wave of entries (wave-uniform) -- the tail of a segment often has
+     * not, and the second evaluation, which could only add zeros, is skipped */
+    for (int base = 0; base < n; base += 128) {
+        const int kk = base + lane_id(), k2 = kk + 64;
+        const bool two = base + 64 < n;
+        double ra = kk < n ? p[kk] : pad;
+        double rb = pad;
+        if (two && k2 < n) rb = p[k2];
+        f(ra, rb, two);
     }
 }
 
@@ -861,11 +865,13 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         double s0 = 0, s1 = 0, s0B = 0, s1B = 0;
         TC_STAGE_SWITCH(ST_SOLVE_UNIFORM, ST_SOLVE_PAIRS);
         auto sweep_list = [&](auto exact) {
-            rl.scan(cnt, hsml, [&](double ra, double rb) {
+            rl.scan(cnt, hsml, [&](double ra, double rb, bool two) {
                 ra = min_f64(ra, hsml);
-                rb = min_f64(rb, hsml);
                 term(exact, ra, s0, s1);
-                term(exact, rb, s0B, s1B);
+                if (two) {
+                    rb = min_f64(rb, hsml);
+                    term(exact, rb, s0B, s1B);
+                }
             });
         };
         if (fd.exact_div) sweep_list(std::true_type());
