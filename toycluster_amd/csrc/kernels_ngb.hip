@@ -816,8 +816,12 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         const double three_h = 3 * inv_h;
         const double nmpart = -mpart;
         const double fpt_h3 = TC_FOURPITHIRD * h3;
-        tc_fdiv fd = tc_fdiv_setup(hf);
-        fd.exact_div = U(fd.exact_div);                     /* one h per wave: a scalar branch, not exec masking */
+        /* tc_fdiv_setup (tc_math.h) with the reciprocal from the unscaled divide core: it is only used when h is
+         * inside the range where that core returns the IEEE bits (exact_div covers the rest) */
+        tc_fdiv fd;
+        fd.b = hf;
+        fd.y = tc_div_f32_lean(1.0f, hf);
+        fd.exact_div = U((int)(((__builtin_bit_cast(uint32_t, hf) & 0x7fffffu) == 0x7fffffu) || !(hf > 1e-30f && hf < 1e30f)));
 
         /* Per-entry arithmetic (src/sph.c:133-153, :426-440), trimmed for the VALU: the f32 quotient
          * u = r/h is still correctly rounded (reciprocal + exact-residual correction); the f64
@@ -911,7 +915,7 @@ __device__ __forceinline__ bool solve_hsml(const List &rl, int cnt, double mpart
         drho_io = (float)dRhodHsml;
         const float hf = (float)hsml;
         /* sph_kernel_WC6(0, hsml): u = 0, t = 1 */
-        float w0 = (float)(TC_WC6_NORM / (double)(hf * hf * hf));
+        float w0 = (float)tc_div_f64_lean(TC_WC6_NORM, (double)(hf * hf * hf));   /* operands in the normal range: same bits */
         double bias_corr = bias_const * mpart * w0;
         rho_out = (float)((double)rho_out + bias_corr);
     }
