@@ -51,3 +51,22 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "tc_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_code_object_guard_accepts_the_libraries_and_refuses_a_tight_limit():
+    """tools/check_codeobj.py (run by the link step of csrc/Makefile): every kernel of both libraries stays inside the
+    short-branch range and carries no long-branch expansion; with an artificially small limit the
+    same tool must fail -- i.e. the guard really looks at the kernels."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_codeobj.py")
+    for name in ("libtcgpu.so", "libtcgpu_m4.so"):
+        lib = os.path.join(os.path.dirname(binding.LIB_PATH), name)
+        if not os.path.exists(lib):
+            import __graft_entry__ as g
+            g.build()
+        ok = subprocess.run([sys.executable, tool, lib], capture_output=True, text=True)
+        assert ok.returncode == 0, ok.stderr[-500:]
+        assert "k_iter" in ok.stdout
+        tight = subprocess.run([sys.executable, tool, lib, "--limit", "50000"], capture_output=True, text=True)
+        assert tight.returncode == 1 and "FAIL" in tight.stderr
