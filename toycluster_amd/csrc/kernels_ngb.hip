@@ -1514,23 +1514,10 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
             const uint32_t jj = dj[sl];
-            const float4 pj = F ? ld4(vmirror, jj) : k.pos4[jj];
-            const float x = pj.x, y = pj.y, z = pj.z, r2 = dr2[sl];
-            const bool b_hb = r2 < hbsq, b_h0 = r2 < h0sq;
-            double r = 0;
-            if (TC_ABLATE(k) != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
-            const uint64_t m_hb = tc_ballot(b_hb), m_in = tc_ballot(b_h0);
-            const uint64_t m_out = m_hb ^ m_in;                       /* h0 < hb: the inner hits are among m_hb */
-            const int slot_in = cs + mask_rank(m_in), slot_out = co + mask_rank(m_out);
-            if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
-                double *dst = b_h0 ? L.in.lds + slot_in : L.out.lds + slot_out;    /* one store per staged hit */
-                if (b_hb) *dst = r;
-            } else {
-                if (b_h0) { if (slot_in < TC_NGBMAX) L.in.put(slot_in, r); }
-                else if (b_hb) { if (slot_out < TC_NGBMAX) L.out.put(slot_out, r); }
-            }
-            cs = U(cs + (int)__popcll(m_in));
-            co = U(co + (int)__popcll(m_out));
+            const float r2 = dr2[sl];
+            /* the gather of the 64 positions is issued first; the sweep's part of the work -- which only needs the
+             * staged index and r2, and every other time runs a whole batch of pair terms -- goes on underneath it */
+            const float4 pj = F ? ld3(vmirror, jj) : k.pos4[jj];        /* 12 bytes: no register of the gather is free for reuse */
             dhead = U((dhead + 64) & (TC_STAGE - 1));
             if (do_wvt) {
                 const bool hwv = r2 < hwsq;
@@ -1551,6 +1538,22 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                 wcnt = U(wcnt + (int)__popcll(mw));
                 if (wcnt >= 64) { convert_w(ftag, 64); wcnt = U(wcnt - 64); }
             }
+            const float x = pj.x, y = pj.y, z = pj.z;
+            const bool b_hb = r2 < hbsq, b_h0 = r2 < h0sq;
+            double r = 0;
+            if (TC_ABLATE(k) != 3) r = pair_r_w(xi, yi, zi, x, y, z, k.boxhalf, k.boxsize, wr);
+            const uint64_t m_hb = tc_ballot(b_hb), m_in = tc_ballot(b_h0);
+            const uint64_t m_out = m_hb ^ m_in;                       /* h0 < hb: the inner hits are among m_hb */
+            const int slot_in = cs + mask_rank(m_in), slot_out = co + mask_rank(m_out);
+            if (cs + 64 <= TC_ICAP && co + 64 <= TC_OCAP) {        /* wave-uniform: everything lands in LDS */
+                double *dst = b_h0 ? L.in.lds + slot_in : L.out.lds + slot_out;    /* one store per staged hit */
+                if (b_hb) *dst = r;
+            } else {
+                if (b_h0) { if (slot_in < TC_NGBMAX) L.in.put(slot_in, r); }
+                else if (b_hb) { if (slot_out < TC_NGBMAX) L.out.put(slot_out, r); }
+            }
+            cs = U(cs + (int)__popcll(m_in));
+            co = U(co + (int)__popcll(m_out));
             wave_lds_fence();
             TC_STAGE_SWITCH(ST_CONVERT_D, ST_TEST);
             return cs + co + TC_STAGE >= TC_NGBMAX;
