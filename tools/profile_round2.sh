@@ -26,6 +26,7 @@ pmc lds     SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_
 pmc grbm    GRBM_GUI_ACTIVE GRBM_COUNT SQ_BUSY_CYCLES SQ_WAVE_CYCLES
 pmc fetch   FETCH_SIZE
 pmc write   WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+[ -x tools/ubench/valu_cost ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o tools/ubench/valu_cost tools/ubench/valu_cost.hip || { echo "valu_cost build failed"; exit 1; }
 ./tools/ubench/valu_cost 4 > $OUT/valu_cost_w4.json 2> $OUT/valu_cost.log || { echo "valu_cost failed"; exit 1; }
 ./tools/ubench/valu_cost 8 > $OUT/valu_cost_w8.json 2>> $OUT/valu_cost.log
 echo profiled
