@@ -113,6 +113,16 @@ double orc_wvt_wc6(float r, float h);
 int orc_reassign_to_halos(int n, const float *pos, double boxsize, int nhalos, const orc_halo *halos,
                           const double *r_sample, int32_t *halo_id, int64_t *perm, int64_t *npart);
 
+/* Attribution experiment (tools/attribute_tail.py; NOT reference behaviour, never set by the parity tests): run the
+ * oracle with one of the GPU library's documented arithmetic deviations injected.  0 = the faithful restatement. */
+#define ORC_DEV_SWEEP_ROUND_ONCE 1   /* WVT displacement: f64 sum at unit step, rounded once (round 2's GPU sweep) */
+#define ORC_DEV_TREE_SUMS        2   /* Find_hsml's three f64 sums as 64 partial sums + a reduction tree */
+#define ORC_DEV_POW_ULP          4   /* every pow() result moved by -1/0/+1 f64 ulp */
+#define ORC_DEV_KERNEL_ULP       8   /* W and W' moved by -1/0/+1 f64 ulp before their f32 rounding */
+void orc_set_deviation(int mask);
+/* number of ball queries that filled the NGBMAX list (tree.c:91-92) since the last reset */
+void orc_truncations(orc_state *s, long *density, long *sweep, int reset);
+
 /* stats of the last orc_find_sph_quantities call */
 void orc_last_stats(const orc_state *s, double *queries_per_part, double *solver_iters_per_part,
                     double *pair_evals_per_part);

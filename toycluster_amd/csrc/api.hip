@@ -168,8 +168,9 @@ static void free_particles(tcgpu_ctx *c)
     TC_FREE(c->apot); TC_FREE(c->bfld); TC_FREE(c->l_apot);
     TC_FREE(c->key); TC_FREE(c->key_sorted); TC_FREE(c->idx); TC_FREE(c->idx_sorted); TC_FREE(c->sort_tmp);
     TC_FREE(c->cells); TC_FREE(c->guess); TC_FREE(c->hwvt); TC_FREE(c->delta); TC_FREE(c->stats); TC_FREE(c->ngb_buf);
-    TC_FREE(c->ustep); TC_FREE(c->rhom_next); TC_FREE(c->prec);
+    TC_FREE(c->ustep); TC_FREE(c->rhom_next); TC_FREE(c->prec); TC_FREE(c->xruns); c->xruns_bytes = 0;
     TC_FREE(c->cum); TC_FREE(c->scan_tmp); TC_FREE(c->mirror); TC_FREE(c->mirror_idx);
+    TC_FREE(c->pf); TC_FREE(c->pf_tmp); c->pf_alloc = 0; c->pf_valid = 0;
     c->cum_alloc = c->mirror_alloc = 0; c->mirror_valid = 0;
     c->cap = 0; c->n = 0; c->nloc = 0; c->nown = 0; c->ncells_alloc = 0;
 }
@@ -879,7 +880,7 @@ static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
 static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
 {
     int rc;
-    c->index_valid = 0; c->mirror_valid = 0; c->ustep_valid = 0;
+    c->index_valid = 0; c->mirror_valid = 0; c->ustep_valid = 0; c->pf_valid = 0;
     if (!multi(c)) full = 1;
     if (full) {
         if ((rc = ensure_pos_all(c))) return rc;
@@ -1072,8 +1073,11 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
         /* one gather per particle serves the density solve and (with_wvt) the WVT sweep that
          * follows on the same positions */
         if ((rc = tc_launch_mirror(c))) return rc;
-        if ((rc = tc_launch_iter(c, with_wvt))) return rc;
-        c->ustep_valid = with_wvt;
+        /* the sweep rides along only in round 2's mode (f64 sums, one rounding); the default sweep reproduces the
+         * reference's order and roundings in a kernel of its own (k_wvt_exact), after the step is known */
+        const int ride = with_wvt && c->sweep_mode == 1;
+        if ((rc = tc_launch_iter(c, ride))) return rc;
+        c->ustep_valid = ride;
     } else if ((rc = tc_launch_density(c))) return rc;
     return 0;
 }
@@ -1185,7 +1189,12 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
             c->local_w_valid = 1;
         }
         if ((rc = tc_launch_commit_rhom(c))) return rc;
-        if ((rc = tc_launch_wvt(c, step))) return rc;
+        if (c->sweep_mode == 0) {
+            /* the exact sweep walks the cells in curve order: their index ranges come from the sorted keys of the
+             * local set (key_sorted stays valid as long as the local order does) */
+            if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;
+            if ((rc = tc_launch_wvt_exact(c, step))) return rc;
+        } else if ((rc = tc_launch_wvt(c, step))) return rc;
     }
     if (move) {
         if ((rc = tc_launch_move(c))) return rc;
@@ -1388,6 +1397,9 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
     else if (!strcmp(name, "blocks_per_cu")) c->blocks_per_cu = (int)value;   /* profiling: cap the persistent grid */
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
+    else if (!strcmp(name, "sweep")) c->sweep_mode = value != 0;         /* 0: the reference's order and roundings (default); 1: f64 sums, rounded once */
+    else if (!strcmp(name, "xsweep_shift")) c->xsweep_shift = (int)value;
+    else if (!strcmp(name, "xsweep_kernel")) c->xsweep_kernel = value != 0;
     else if (!strcmp(name, "curl_literal")) c->curl_literal = value != 0;
     else if (!strcmp(name, "no_records")) c->no_records = value != 0;    /* tests: the fall-back of k_prec / k_cprec */
     else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = c->lmax_rm0 = 0; }

@@ -26,6 +26,7 @@
 #include <type_traits>
 #include "tc_ctx.h"
 #include "tc_lean.h"
+#include "tc_hilbert_lut.h"
 
 /* Stage ablation for instruction-count profiling (tools/ablate_iter.py) is compiled in only with
  * -DTC_PROFILE_ABLATE (make ablate -> ../lib/libtcgpu_ablate.so); the product kernels carry no such branches. */
@@ -1296,6 +1297,554 @@ int tc_launch_wvt(tcgpu_ctx *c, double step)
     tc_phase_begin(c, PH_WVT);
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     k_wvt<<<grid_for(c, nloc, k_wvt), TBN, 0, c->stream>>>(a);
+    tc_phase_end(c);
+    TC_HIP(c, hipGetLastError());
+    return 0;
+}
+
+/* ------------------------------------------------------------------ K9 exact: the sweep in the reference's order
+ *
+ * src/wvt_relax.c:167-169 adds every neighbour's term to a FLOAT accumulator (`delta[k][ipart] += ...`), in the order
+ * Find_ngb_tree emits the list: ascending particle index (src/tree.c:25-111 walks the depth-first node array, whose
+ * leaves tile [0, N) in ascending order).  A sum rounded after every addend depends on that order, so the displacement
+ * can only be reproduced bit for bit by visiting the neighbours in ascending index and rounding where the reference
+ * rounds.  round 2's sweep (k_wvt / the fused kernel: f64 partial sums over 64 lanes, one rounding) differs from it by
+ * ~1e-6 |delta| per iteration -- the one systematic input difference between this library and the reference, and the
+ * owner of the parity tail (tools/attribute_tail.py).
+ *
+ * One LANE per particle here (a sequentially rounded sum is a serial chain: a wavefront per particle would keep
+ * three lanes busy), 64 Peano-consecutive particles per wavefront, three phases:
+ *   A1  every lane walks the implicit octree of the cell table depth-first with the children of a node taken in
+ *       CURVE order (TC_HILBERT_INV: the 24 orientations of the reference's transform), descending only into cells
+ *       the ball overlaps, and notes the index runs of the overlapped cells of its query level -- they come out in
+ *       ascending index, adjacent ones merged (per-wave scratch, [slot][lane]);
+ *   A2  the lane walks its runs, tests every particle with the reference's all-f32 predicate (src/tree.c:67-89) and
+ *       appends the hits to a per-lane LDS buffer, stopping like the reference at the NGBMAX-th hit (src/tree.c:91-92);
+ *   B   whenever a buffer is full the lanes evaluate their buffered hits: src/wvt_relax.c:141-169 statement for
+ *       statement -- f32 differences scaled in f64, f32 folding, f32 r2, (float)sqrt, f32 quotient, the f64 kernel
+ *       polynomial multiplied out left to right, ((step * h_i) * wk) * d / r in f64, and the f32 accumulator rounded
+ *       after each neighbour.  Divisions and roots use the unscaled cores of tc_lean.h where the operands are in the
+ *       normal range (the IEEE bits, verified operand by operand) and the IEEE sequences otherwise.
+ * No f64 value here depends on summation order, so the result does not depend on wave scheduling, grid size or on
+ * how particles are split over ranks.
+ */
+#define TC_XHITS 48            /* buffered hits per lane (LDS: 4 B x 64 lanes x TC_XHITS per wave) */
+#define TC_XRUNCAP 384         /* index runs per lane (after merging; <= 8^3 cells of the query level, about half inside the ball) */
+
+struct tc_xwvt_args {
+    tc_dev_const k;
+    double step;
+    float *delta;       /* 3n xyz interleaved, G order */
+    const uint32_t *lg; /* local slot -> G index */
+    const float *hsml0; /* the carried smoothing lengths the pass started from (level ranges of a sharded pass) */
+    int *flags;
+    uint2 *runs;        /* per wave: TC_XRUNCAP x 64 */
+    int xshift;         /* added to the query level (tuning: coarser leaves = fewer cells to walk, more candidates to test) */
+    int orphans_only;   /* k_wvt_exact: run only when the local set has orphans (k_wvt_exact4 did the launch otherwise) */
+    int dbg;            /* profiling only (results invalid): 1 = stop after A1, 2 = no B */
+};
+
+/* periodic distance (one dimension) from x to the cell [c s, (c + 1) s) of a ring of circumference box; 0 inside */
+__device__ __forceinline__ float cell_gap(float x, int c, float s, float box)
+{
+    const float clo = (float)c * s, chi = clo + s;
+    float g = fmaxf(fmaxf(clo - x, x - chi), 0.0f);
+    const float alt = fmaxf(box - s - g, 0.0f);            /* the other way round the ring */
+    return fminf(g, alt);
+}
+
+/* groups of 64 consecutive work items, XCD-aware like work_queue(): f(first, stop) */
+template <class F>
+__device__ __forceinline__ void work_queue64(const tc_dev_const &k, F &&f)
+{
+    const int lo = k.lo, hi = k.hi;
+    const bool grouped = gridDim.x >= 16 && (gridDim.x & 7) == 0;
+    const int ngroups = grouped ? 8 : 1;
+    int glen = grouped ? ((hi - lo + 7) >> 3) : (hi - lo);
+    glen = (glen + 63) & ~63;
+    const int g0 = grouped ? (int)(blockIdx.x & 7) : 0;
+    for (int gg = 0; gg < ngroups; gg++) {
+        const int grp = (g0 + gg) & (ngroups - 1);
+        const int gstart = lo + grp * glen;
+        int gend = gstart + glen;
+        if (gend > hi) gend = hi;
+        if (gend <= gstart) continue;
+        for (;;) {
+            uint32_t got = 0;
+            if ((threadIdx.x & 63) == 0)
+                got = atomicAdd(reinterpret_cast<unsigned int *>(&k.work_ctr[16 * grp]), 64u);
+            got = U(got);
+            if (got >= (uint32_t)(gend - gstart)) break;
+            const int base = gstart + (int)got;
+            f(base, base + 64 < gend ? base + 64 : gend);
+        }
+    }
+}
+
+/* A1 of the exact sweep: the index runs of the level-Lq cells the ball (padded radius^2 hp2) overlaps, in ascending
+ * index, adjacent ones merged; one lane per particle; entry s of this lane's list at runs[64 s].  Returns the count. */
+__device__ __forceinline__ int ordered_runs(const tc_dev_const &k, bool valid, float xi, float yi, float zi, float hp2, int Lq,
+                                            const tc_level_desc &D, const unsigned char *lds_inv, uint2 *runs, int *flags)
+{
+    const float boxf = k.boxsize_f;
+    /* ---- A1: overlapped cells of level Lq in curve order -> index runs */
+    int l = valid ? 1 : 0;
+    int cx = 0, cy = 0, cz = 0;          /* the node (level l - 1) whose children are being enumerated */
+    uint32_t dig = 0;                    /* 3 bits per level: next child (curve order) */
+    uint64_t sts = 0;                    /* 5 bits per level: orientation of the node at that level (root: 0) */
+    uint32_t cur_f = 0, cur_e = 0;
+    int nruns = 0;
+    while (tc_ballot(l > 0)) {
+        if (l > 0) {
+            const int s3 = 3 * (l - 1);
+            const uint32_t d = (dig >> s3) & 7u;
+            const uint32_t st = (uint32_t)(sts >> (5 * (l - 1))) & 31u;
+            const uint32_t e = lds_inv[st * 8 + d];
+            const int ccx = 2 * cx + (int)(e & 1u), ccy = 2 * cy + (int)((e >> 2) & 1u), ccz = 2 * cz + (int)((e >> 1) & 1u);
+            const float s = __builtin_ldexpf(boxf, -l);
+            const float gx = cell_gap(xi, ccx, s, boxf), gy = cell_gap(yi, ccy, s, boxf), gz = cell_gap(zi, ccz, s, boxf);
+            const bool ov = gx * gx + gy * gy + gz * gz <= hp2;
+            bool advance = true;
+            if (ov) {
+                if (l == Lq) {
+                    const int ix = ccx - D.ox, iy = ccy - D.oy, iz = ccz - D.oz;
+                    if (ix >= 0 && ix < D.nx && iy >= 0 && iy < D.ny && iz >= 0 && iz < D.nz) {
+                        const uint2 ce = k.cells[(size_t)D.off + ((size_t)ix * D.ny + iy) * D.nz + iz];
+                        const uint32_t f0 = ~ce.x, e0 = ce.y;
+                        if (e0 > f0) {
+                            if (cur_e > cur_f && f0 == cur_e) cur_e = e0;          /* adjacent in index: one run */
+                            else {
+                                if (cur_e > cur_f) {
+                                    if (nruns < TC_XRUNCAP) runs[(size_t)nruns * 64] = make_uint2(cur_f, cur_e);
+                                    nruns++;
+                                }
+                                cur_f = f0; cur_e = e0;
+                            }
+                        }
+                    }
+                } else {
+                    cx = ccx; cy = ccy; cz = ccz;
+                    sts = (sts & ~(31ull << (5 * l))) | ((uint64_t)(e >> 3) << (5 * l));
+                    l++;
+                    dig &= ~(7u << (3 * (l - 1)));
+                    advance = false;
+                }
+            }
+            if (advance) {
+                for (;;) {
+                    const int q3 = 3 * (l - 1);
+                    if (((dig >> q3) & 7u) < 7u) { dig += 1u << q3; break; }
+                    dig &= ~(7u << q3);
+                    l--;
+                    if (l == 0) break;
+                    cx >>= 1; cy >>= 1; cz >>= 1;
+                }
+            }
+        }
+    }
+    if (cur_e > cur_f) {
+        if (nruns < TC_XRUNCAP) runs[(size_t)nruns * 64] = make_uint2(cur_f, cur_e);
+        nruns++;
+    }
+    if (nruns > TC_XRUNCAP) { atomicOr(&flags[3], 1); nruns = TC_XRUNCAP; }
+    return nruns;
+}
+
+__global__ __launch_bounds__(TBN) void k_wvt_exact(tc_xwvt_args a)
+{
+    __shared__ uint32_t lds_hits[WPB * TC_XHITS * 64];
+    __shared__ unsigned char lds_inv[TC_HILBERT_NSTATES * 8];
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES * 8; t += TBN) lds_inv[t] = TC_HILBERT_INV[t];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t *hits = lds_hits + (size_t)wave * (TC_XHITS * 64) + lane;            /* entry s at hits[64 s] */
+    uint2 *runs = a.runs + (size_t)(blockIdx.x * WPB + wave) * ((size_t)TC_XRUNCAP * 64) + lane;
+    const tc_dev_const &k = a.k;
+    const double boxinv = k.boxinv;
+    int norph = *k.norph;
+    if (norph > TC_MAX_ORPHANS) norph = TC_MAX_ORPHANS;
+    if (a.orphans_only && norph == 0) return;
+
+    work_queue64(k, [&](int base, int stop) {
+        const int t = base + lane;
+        const bool valid = t < stop;
+        const int tt = valid ? t : base;
+        const int i = k.own ? (int)k.own[tt] : tt;
+        const float4 pi = k.pos4[i];
+        const float xi = pi.x, yi = pi.y, zi = pi.z;
+        const float hq = (float)((double)pi.w * k.boxsize);             /* src/wvt_relax.c:135 */
+        const float hq2 = hq * hq;
+        /* query level: the table levels this particle's queries may use (sharded passes: tc_particle_levels) */
+        int lmin = k.lmin_tab, lmaxp = k.lmax;
+        if (k.margin_on) {
+            const float h0 = a.hsml0[i];
+            const float rg = tc_margin_radius(h0, pi.w, k.boxsize, k.margin_widen);
+            tc_particle_levels(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmax, h0, rg, &lmin, &lmaxp);
+        }
+        const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
+        const tc_level_desc D = k.lvl[Lq];
+        /* padded radius: the f32 predicate can accept pairs a few ulp beyond hq, and the cell bounds below are f32
+         * products of magnitude boxsize */
+        const float hp = (float)((double)hq * (1.0 + 1e-5) + k.boxsize * 4e-6);
+        const float hp2 = hp * hp;
+
+        const int nruns = ordered_runs(k, valid, xi, yi, zi, hp2, Lq, D, lds_inv, runs, a.flags);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        /* Orphans (a coordinate == boxsize: not in the cell table, k_cells) are tested one by one and merged into the
+         * ascending order by index; `opend` = the smallest orphan index not yet considered.  None exist in practice. */
+        auto next_orphan = [&](int after) -> uint32_t {
+            uint32_t best = 0xffffffffu;
+            for (int o = 0; o < norph; o++) {
+                const uint32_t jo = k.orphans[o];
+                if ((int)jo > after && jo < best) best = jo;
+            }
+            return best;
+        };
+        uint32_t opend = norph ? next_orphan(-1) : 0xffffffffu;
+
+        /* ---- A2 / B */
+        int ri = 0;
+        uint32_t j = 0, jend = 0;
+        int nlist = 0;                       /* length of the reference's list so far (self included) */
+        bool cdone = !valid;
+        float d0 = 0, d1 = 0, d2 = 0;
+        const double step_hi = a.step * (double)pi.w;                   /* step * hsml[ipart], src/wvt_relax.c:167 */
+        for (;;) {
+            int cnt = 0;
+            while (!tc_ballot(cnt >= TC_XHITS) && tc_ballot(!cdone)) {
+                if (!cdone) {
+                    if (j == jend) {
+                        if (ri < nruns) {
+                            const uint2 r = runs[(size_t)ri * 64];
+                            ri++;
+                            j = r.x; jend = r.y;
+                        } else j = jend = 0xffffffffu;                  /* only orphans left, if any */
+                    }
+                    /* next item in ascending index: the run's next particle, or an orphan due before it */
+                    uint32_t jc = 0;
+                    bool take = false, from_run = false;
+                    if (norph && opend < j) {
+                        jc = opend;
+                        opend = next_orphan((int)opend);
+                        take = true;
+                    } else if (j != 0xffffffffu) {
+                        jc = j++;
+                        take = from_run = true;
+                    }
+                    if (take) {
+                        const float4 p = k.pos4[jc];
+                        /* an orphan met inside a run's index range waits for its turn as an orphan */
+                        const bool mine = !(norph && from_run && is_orphan(k, p));
+                        const float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+                        if (mine && r2 < hq2) {
+                            hits[64 * cnt] = jc;
+                            cnt++;
+                            if (++nlist == TC_NGBMAX) { cdone = true; atomicAdd(&a.flags[4], 1); }   /* src/tree.c:91-92 */
+                        }
+                    } else cdone = true;
+                }
+            }
+            for (int s = 0; tc_ballot(s < cnt); s++) {
+                if (s < cnt) {
+                    const uint32_t jj = hits[64 * s];
+                    if ((int)jj != i) {                                 /* src/wvt_relax.c:141-142 */
+                        const float4 pj = k.pos4[jj];
+                        float dx = (float)((double)(xi - pj.x) * boxinv);
+                        float dy = (float)((double)(yi - pj.y) * boxinv);
+                        float dz = (float)((double)(zi - pj.z) * boxinv);
+                        dx = (double)dx > 0.5 ? dx - 1.0f : dx;         /* src/wvt_relax.c:148-154 */
+                        dy = (double)dy > 0.5 ? dy - 1.0f : dy;
+                        dz = (double)dz > 0.5 ? dz - 1.0f : dz;
+                        dx = (double)dx < -0.5 ? dx + 1.0f : dx;
+                        dy = (double)dy < -0.5 ? dy + 1.0f : dy;
+                        dz = (double)dz < -0.5 ? dz + 1.0f : dz;
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        const float h = (float)(0.5 * (double)(pi.w + pj.w));
+                        if (!(r2 > h * h)) {
+                            double e0, e1, e2;
+                            if (r2 < 1e-24f) {                          /* coincident particles: the IEEE sequences (0 / 0 and all) */
+                                const float r = sqrtf(r2);
+                                const float wk = (float)tc_wvt_wc6(r, h);
+                                e0 = step_hi * (double)wk * (double)dx / (double)r;
+                                e1 = step_hi * (double)wk * (double)dy / (double)r;
+                                e2 = step_hi * (double)wk * (double)dz / (double)r;
+                            } else {
+                                const float r = tc_sqrt_f32_lean_pos(r2);            /* == (float)sqrt((double)r2) */
+                                const double u = (double)tc_div_f32_lean(r, h);      /* src/wvt_relax.c:277: f32 quotient */
+                                const double tq = 1 - u;
+                                const float wk = (float)(TC_WC6_NORM * tq * tq * tq * tq * tq * tq * tq * tq
+                                                         * (1 + 8 * u + 25 * u * u + 32 * u * u * u));
+                                const double b = step_hi * (double)wk;
+                                const double rd = (double)r;
+                                /* three quotients by the same r: one reciprocal refinement, then the residual
+                                 * correction of tc_div_f64_lean per numerator */
+                                double y = __builtin_amdgcn_rcp(rd);
+                                double ee = __builtin_fma(-rd, y, 1.0);
+                                y = __builtin_fma(y, ee, y);
+                                ee = __builtin_fma(-rd, y, 1.0);
+                                y = __builtin_fma(y, ee, y);
+                                const double n0 = b * (double)dx, n1 = b * (double)dy, n2 = b * (double)dz;
+                                const double q0 = n0 * y, q1 = n1 * y, q2 = n2 * y;
+                                e0 = __builtin_fma(__builtin_fma(-rd, q0, n0), y, q0);
+                                e1 = __builtin_fma(__builtin_fma(-rd, q1, n1), y, q1);
+                                e2 = __builtin_fma(__builtin_fma(-rd, q2, n2), y, q2);
+                            }
+                            d0 = (float)((double)d0 + e0);              /* src/wvt_relax.c:167-169: rounded per neighbour */
+                            d1 = (float)((double)d1 + e1);
+                            d2 = (float)((double)d2 + e2);
+                        }
+                    }
+                }
+            }
+            if (!tc_ballot(!cdone)) break;
+        }
+        if (valid) {
+            const size_t g = a.lg[i];
+            a.delta[3 * g] = d0;
+            a.delta[3 * g + 1] = d1;
+            a.delta[3 * g + 2] = d2;
+        }
+    });
+}
+
+/* The same sweep with FOUR lanes per particle for the two phases that touch memory (the launch's normal kernel; a
+ * local set with orphans takes k_wvt_exact above).  A1 runs one lane per particle as above; then, 16 particles at a
+ * time, a quad walks its particle's runs four candidates per step -- one 64-byte read instead of four scattered ones --
+ * keeps the hits' positions (in ascending index: rank inside the step from the quad's lane mask) in LDS, and evaluates
+ * buffered hits four at a time; the f32 accumulator then takes the four terms in order, passed through the quad with
+ * DPP (the order and every rounding of src/wvt_relax.c:167-169). */
+#define TC_X4CAP 32            /* buffered hit positions per particle */
+
+__device__ __forceinline__ uint32_t quad_bits(uint64_t ballot, int lane)
+{
+    return (uint32_t)(ballot >> (lane & 60)) & 15u;
+}
+
+__device__ __forceinline__ float quad_bcast(float v, int kk)
+{
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (kk) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, false); break;
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, false); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0xaa, 0xf, 0xf, false); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0xff, 0xf, 0xf, false); break;
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+__global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
+{
+    __shared__ __align__(16) float4 lds_hits4[WPB * 16 * TC_X4CAP];
+    __shared__ int lds_nruns[WPB * 64];
+    __shared__ unsigned char lds_inv[TC_HILBERT_NSTATES * 8];
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES * 8; t += TBN) lds_inv[t] = TC_HILBERT_INV[t];
+    __syncthreads();
+    const tc_dev_const &k = a.k;
+    if (*k.norph > 0) return;                                   /* k_wvt_exact does this launch */
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int q = lane >> 2, lq = lane & 3;
+    const uint32_t below = (1u << lq) - 1u;
+    float4 *buf = lds_hits4 + ((size_t)wave * 16 + q) * TC_X4CAP;
+    int *nr = lds_nruns + wave * 64;
+    uint2 *wruns = a.runs + (size_t)(blockIdx.x * WPB + wave) * ((size_t)TC_XRUNCAP * 64);
+    const double boxinv = k.boxinv;
+
+    work_queue64(k, [&](int base, int stop) {
+        /* ---- A1, one lane per particle */
+        {
+            const int t = base + lane;
+            const bool valid = t < stop;
+            const int tt = valid ? t : base;
+            const int i = k.own ? (int)k.own[tt] : tt;
+            const float4 pi = k.pos4[i];
+            const float hq = (float)((double)pi.w * k.boxsize);
+            int lmin = k.lmin_tab, lmaxp = k.lmax;
+            if (k.margin_on) {
+                const float h0 = a.hsml0[i];
+                const float rg = tc_margin_radius(h0, pi.w, k.boxsize, k.margin_widen);
+                tc_particle_levels(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmax, h0, rg, &lmin, &lmaxp);
+            }
+            const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
+            const tc_level_desc D = k.lvl[Lq];
+            const float hp = (float)((double)hq * (1.0 + 1e-5) + k.boxsize * 4e-6);
+            nr[lane] = ordered_runs(k, valid, pi.x, pi.y, pi.z, hp * hp, Lq, D, lds_inv, wruns + lane, a.flags);
+        }
+        /* the runs were written one lane per particle and are read by the particle's quad */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wave_lds_fence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        if (a.dbg & 1) return;
+        /* ---- A2 / B, four lanes per particle, 16 particles per pass */
+        for (int pass = 0; pass < 4; pass++) {
+            if (base + 16 * pass >= stop) break;
+            const int pl = 16 * pass + q;
+            const int t = base + pl;
+            const bool valid = t < stop;
+            const int tt = valid ? t : base;
+            const int i = k.own ? (int)k.own[tt] : tt;
+            const float4 pi = k.pos4[i];
+            const float xi = pi.x, yi = pi.y, zi = pi.z;
+            const float hq = (float)((double)pi.w * k.boxsize);             /* src/wvt_relax.c:135 */
+            const float hq2 = hq * hq;
+            const int nruns = nr[pl];
+            const uint2 *pruns = wruns + pl;
+            const double step_hi = a.step * (double)pi.w;                   /* step * hsml[ipart], src/wvt_relax.c:167 */
+            int ri = 0, nlist = 0, cnt = 0;
+            uint32_t j = 0, jend = 0;
+            bool cdone = !valid;
+            float d0 = 0, d1 = 0, d2 = 0;
+            for (;;) {
+                while (!tc_ballot(cnt > TC_X4CAP - 4) && tc_ballot(!cdone)) {
+                    if (!cdone && j >= jend) {
+                        if (ri < nruns) {
+                            const uint2 r = pruns[(size_t)ri * 64];
+                            ri++;
+                            j = r.x; jend = r.y;
+                        } else cdone = true;
+                    }
+                    const uint32_t jc = j + (uint32_t)lq;
+                    const bool act = !cdone && jc < jend;
+                    const float4 p = k.pos4[act ? jc : (uint32_t)i];
+                    const float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+                    const bool hit = act && r2 < hq2;
+                    const uint32_t mh = quad_bits(tc_ballot(hit), lane);
+                    /* the reference's list ends at its NGBMAX-th entry (src/tree.c:91-92); the particle itself is on the
+                     * list but not in the sum (src/wvt_relax.c:141-142) */
+                    const bool keep = hit && nlist + (int)__popc(mh & below) < TC_NGBMAX && jc != (uint32_t)i;
+                    const uint32_t mk = quad_bits(tc_ballot(keep), lane);
+                    if (keep) buf[cnt + (int)__popc(mk & below)] = p;
+                    cnt += (int)__popc(mk);
+                    nlist += (int)__popc(mh);
+                    if (!cdone) {
+                        j += 4;
+                        if (nlist >= TC_NGBMAX) {
+                            cdone = true;
+                            if (lq == 0) atomicAdd(&a.flags[4], 1);
+                        }
+                    }
+                }
+                wave_lds_fence();
+                if (a.dbg & 2) cnt = 0;
+                for (int s = 0; tc_ballot(s < cnt); s += 4) {
+                    const bool ok = s + lq < cnt;
+                    const float4 pj = buf[ok ? s + lq : 0];
+                    float dx = (float)((double)(xi - pj.x) * boxinv);
+                    float dy = (float)((double)(yi - pj.y) * boxinv);
+                    float dz = (float)((double)(zi - pj.z) * boxinv);
+                    dx = dx > 0.5f ? dx - 1.0f : dx;                    /* src/wvt_relax.c:148-154 (0.5 is exact in f32) */
+                    dy = dy > 0.5f ? dy - 1.0f : dy;
+                    dz = dz > 0.5f ? dz - 1.0f : dz;
+                    dx = dx < -0.5f ? dx + 1.0f : dx;
+                    dy = dy < -0.5f ? dy + 1.0f : dy;
+                    dz = dz < -0.5f ? dz + 1.0f : dz;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    const float h = (float)(0.5 * (double)(pi.w + pj.w));
+                    const bool in = ok && !(r2 > h * h);
+                    double e0 = 0, e1 = 0, e2 = 0;
+                    {
+                        const float r = tc_sqrt_f32_lean_pos(r2);                /* == (float)sqrt((double)r2) */
+                        const double u = (double)tc_div_f32_lean(r, h);          /* src/wvt_relax.c:277: f32 quotient */
+                        const double tq = 1 - u;
+                        const float wk = (float)(TC_WC6_NORM * tq * tq * tq * tq * tq * tq * tq * tq
+                                                 * (1 + 8 * u + 25 * u * u + 32 * u * u * u));
+                        const double b = step_hi * (double)wk;
+                        const double rd = (double)r;
+                        /* three quotients by the same r: one reciprocal refinement, then the residual correction
+                         * of tc_div_f64_lean per numerator */
+                        double y = __builtin_amdgcn_rcp(rd);
+                        double ee = __builtin_fma(-rd, y, 1.0);
+                        y = __builtin_fma(y, ee, y);
+                        ee = __builtin_fma(-rd, y, 1.0);
+                        y = __builtin_fma(y, ee, y);
+                        const double n0 = b * (double)dx, n1 = b * (double)dy, n2 = b * (double)dz;
+                        const double q0 = n0 * y, q1 = n1 * y, q2 = n2 * y;
+                        if (in) {
+                            e0 = __builtin_fma(__builtin_fma(-rd, q0, n0), y, q0);
+                            e1 = __builtin_fma(__builtin_fma(-rd, q1, n1), y, q1);
+                            e2 = __builtin_fma(__builtin_fma(-rd, q2, n2), y, q2);
+                        }
+                    }
+                    if (tc_ballot(in && r2 < 1e-24f)) {                 /* coincident particles: the IEEE sequences (0 / 0 and all) */
+                        if (in && r2 < 1e-24f) {
+                            const float r = sqrtf(r2);
+                            const float wk = (float)tc_wvt_wc6(r, h);
+                            e0 = step_hi * (double)wk * (double)dx / (double)r;
+                            e1 = step_hi * (double)wk * (double)dy / (double)r;
+                            e2 = step_hi * (double)wk * (double)dz / (double)r;
+                        }
+                    }
+                    /* src/wvt_relax.c:167-169: the f32 accumulator takes the four terms in order, rounded after each
+                     * (a lane without a term adds 0.0, which changes nothing) */
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const float n0 = (float)((double)d0 + e0), n1 = (float)((double)d1 + e1), n2 = (float)((double)d2 + e2);
+                        d0 = quad_bcast(n0, kk); d1 = quad_bcast(n1, kk); d2 = quad_bcast(n2, kk);
+                    }
+                }
+                cnt = 0;
+                wave_lds_fence();
+                if (!tc_ballot(!cdone)) break;
+            }
+            if (valid && lq == 0) {
+                const size_t g = a.lg[i];
+                a.delta[3 * g] = d0;
+                a.delta[3 * g + 1] = d1;
+                a.delta[3 * g + 2] = d2;
+            }
+        }
+    });
+}
+
+template <class K>
+static int xgrid(const tcgpu_ctx *c, int nloc, K kernel)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBN, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (c->blocks_per_cu > 0 && c->blocks_per_cu < per_cu) per_cu = c->blocks_per_cu;
+    int need = (nloc + 64 * WPB - 1) / (64 * WPB);
+    int cap = c->num_cu * per_cu;
+    if (cap > TC_MAX_PERSISTENT_BLOCKS) cap = TC_MAX_PERSISTENT_BLOCKS;
+    int g = need < cap ? need : cap;
+    if (g >= 16) g &= ~7;
+    return g;
+}
+
+int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
+{
+    tc_xwvt_args a;
+    tc_fill_const(c, &a.k);
+    a.step = step;
+    a.delta = c->delta;
+    a.lg = c->lg;
+    a.hsml0 = c->hsml0;
+    a.flags = c->flags;
+    a.xshift = c->xsweep_shift;
+    a.dbg = c->ablate;
+    int nloc = a.k.hi - a.k.lo;
+    if (nloc <= 0) return 0;
+    const int g4 = xgrid(c, nloc, k_wvt_exact4), g1 = xgrid(c, nloc, k_wvt_exact);
+    const size_t want = (size_t)(g4 > g1 ? g4 : g1) * WPB * TC_XRUNCAP * 64 * sizeof(uint2);
+    if (c->xruns_bytes < want) {
+        if (c->xruns) TC_HIP(c, hipFree(c->xruns));
+        c->xruns = nullptr; c->xruns_bytes = 0;
+        TC_HIP(c, hipMalloc(&c->xruns, want));
+        c->xruns_bytes = want;
+    }
+    a.runs = (uint2 *)c->xruns;
+    tc_phase_begin(c, PH_WVT);
+    /* option "xsweep_kernel" = 1 (tests): the one-lane-per-particle kernel for every launch; by default it only runs
+     * when the local set has orphans (a device-side count: both kernels are launched, one returns at once) */
+    if (!c->xsweep_kernel) {
+        TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
+        a.orphans_only = 1;
+        k_wvt_exact4<<<g4, TBN, 0, c->stream>>>(a);
+    }
+    a.orphans_only = !c->xsweep_kernel;
+    TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
+    k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;

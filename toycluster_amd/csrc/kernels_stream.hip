@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <rocprim/rocprim.hpp>
+#include <iterator>
 #include "tc_ctx.h"
 #include "tc_hilbert_lut.h"
 
@@ -911,6 +912,84 @@ int tc_launch_cells(tcgpu_ctx *c)
     TC_HIP(c, hipGetLastError());
     c->index_valid = 1;
     c->mirror_valid = 0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ K4p cell starts in CURVE order
+
+ * pf[L][p] = index of the first particle whose Peano key has a level-L prefix >= p, p = 0 .. 8^L (pf[L][8^L] = n): the
+ * cells of a level taken in curve order are consecutive index ranges, so the particles of the cells p .. q are
+ * [pf[L][p], pf[L][q + 1]) -- what the ordered traversal of the exact WVT sweep (k_wvt_exact4) turns its key ranges
+ * into.  Built from the sorted keys: heads of runs are marked, empty cells take the head of the next occupied one
+ * (one reverse running minimum over the whole table; level t's entries carry the bias t (n + 1) so that the minimum
+ * never crosses from one level into the previous one).  Keys, not positions, decide membership: a particle with a
+ * coordinate == boxsize ("orphan", k_cells) sits in the cell its key names and is found there. */
+__global__ __launch_bounds__(TB) void k_pf_mark(const tc_u128 *__restrict__ key, int n, int lmin, int lmax, uint32_t *__restrict__ pf)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {                                             /* the end marker of every level */
+        uint32_t off = 0;
+        for (int L = lmin; L <= lmax; L++) {
+            const uint32_t cells = 1u << (3 * L);
+            pf[off + cells] = (uint32_t)n + (uint32_t)(L - lmin) * (uint32_t)(n + 1);
+            off += cells + 1;
+        }
+        return;
+    }
+    const tc_u128 k = key[i];
+    const tc_u128 kp = i > 0 ? key[i - 1] : 0;
+    uint32_t off = 0;
+    for (int L = lmin; L <= lmax; L++) {
+        const uint32_t cells = 1u << (3 * L);
+        const uint32_t p = (uint32_t)(k >> (128 - 3 * L)), pp = (uint32_t)(kp >> (128 - 3 * L));
+        if (i == 0 || p != pp) pf[off + p] = (uint32_t)i + (uint32_t)(L - lmin) * (uint32_t)(n + 1);
+        off += cells + 1;
+    }
+}
+
+size_t tc_pf_entries(int lmin, int lmax)
+{
+    size_t t = 0;
+    for (int L = lmin; L <= lmax; L++) t += ((size_t)1 << (3 * L)) + 1;
+    return t;
+}
+
+int tc_pf_temp_bytes(size_t nent, size_t *bytes)
+{
+    size_t b = 0;
+    auto it = std::make_reverse_iterator((uint32_t *)nullptr + nent);
+    hipError_t e = rocprim::inclusive_scan(nullptr, b, it, it, nent, rocprim::minimum<uint32_t>());
+    *bytes = b;
+    return e == hipSuccess ? 0 : -1;
+}
+
+int tc_launch_pfirst(tcgpu_ctx *c)
+{
+    const int n = (int)c->nloc;
+    const int lmin = c->lmin_tab, lmax = c->lmax;
+    c->pf_valid = 0;
+    if ((uint64_t)(lmax - lmin + 1) * (uint64_t)(n + 1) >= 0xffffffffull) TC_FAIL(c, TCGPU_ERR_ARG, "cell-start table: too many particles for the level bias");
+    const size_t nent = tc_pf_entries(lmin, lmax);
+    if (nent > c->pf_alloc) {
+        hipFree(c->pf); hipFree(c->pf_tmp);
+        c->pf = nullptr; c->pf_tmp = nullptr; c->pf_alloc = 0;
+        TC_HIP(c, hipMalloc(&c->pf, nent * sizeof(uint32_t)));
+        if (tc_pf_temp_bytes(nent, &c->pf_tmp_bytes)) TC_FAIL(c, TCGPU_ERR_HIP, "scan temp query failed");
+        TC_HIP(c, hipMalloc(&c->pf_tmp, c->pf_tmp_bytes ? c->pf_tmp_bytes : 16));
+        c->pf_alloc = nent;
+    }
+    tc_phase_begin(c, PH_CELLS);
+    TC_HIP(c, hipMemsetAsync(c->pf, 0xff, nent * sizeof(uint32_t), c->stream));
+    k_pf_mark<<<(n + 1 + TB - 1) / TB, TB, 0, c->stream>>>(c->key_sorted, n, lmin, lmax, c->pf);
+    auto it = std::make_reverse_iterator(c->pf + nent);
+    size_t b = c->pf_tmp_bytes;
+    hipError_t e = rocprim::inclusive_scan(c->pf_tmp, b, it, it, nent, rocprim::minimum<uint32_t>(), c->stream);
+    tc_phase_end(c);
+    TC_HIP(c, e);
+    TC_HIP(c, hipGetLastError());
+    c->pf_lmin = lmin;
+    c->pf_valid = 1;
     return 0;
 }
 

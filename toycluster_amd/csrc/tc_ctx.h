@@ -207,6 +207,16 @@ struct tcgpu_ctx {
     float *rhom_next;             /* cap: model density at the current positions, committed by the sweep (G order) */
     int ustep_valid;              /* ustep belongs to the current local order and positions */
     int fuse;                     /* option: use the fused kernel (default 1) */
+    int sweep_mode;               /* option "sweep": 0 = the reference's f32 accumulation in ascending index (k_wvt_exact, default),
+                                   * 1 = round 2's f64 sums rounded once (fused into k_iter, or k_wvt) */
+    int xsweep_shift;             /* option "xsweep_shift": added to the query level of k_wvt_exact (tuning) */
+    int xsweep_kernel;            /* option "xsweep_kernel" (tests): 1 = the one-lane-per-particle kernel for every launch */
+    uint32_t *pf;                 /* cell starts in curve order, levels pf_lmin..lmax (tc_launch_pfirst); entries carry a per-level bias */
+    void *pf_tmp;
+    size_t pf_alloc, pf_tmp_bytes;
+    int pf_lmin, pf_valid;        /* ... built for the current local order */
+    void *xruns;                  /* per-wave index runs of k_wvt_exact, on demand */
+    size_t xruns_bytes;
     int num_cu;
     int blocks_per_cu;            /* profiling only: cap on the co-resident blocks per CU of the persistent kernels (0 = all) */
     uint32_t *orphans;
@@ -342,6 +352,7 @@ int tc_launch_gather_local(tcgpu_ctx *c);       /* lg, pos4, hsml in sorted loca
 int tc_launch_cells(tcgpu_ctx *c);
 int tc_scan_temp_bytes(size_t ncell, size_t *bytes);
 int tc_launch_mirror(tcgpu_ctx *c);             /* cum, mirror, mirror_idx from cells + pos4 */
+int tc_launch_pfirst(tcgpu_ctx *c);             /* pf from the sorted keys of the local set */
 int tc_launch_guess(tcgpu_ctx *c);
 int tc_launch_scatter_results(tcgpu_ctx *c);    /* hsml, rho, vhf of the own particles -> G order */
 /* global arrays */
@@ -364,6 +375,7 @@ int tc_launch_density(tcgpu_ctx *c);
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt);   /* fused density (+ unit-step WVT sums) */
 int tc_launch_apply_step(tcgpu_ctx *c, double step);  /* delta (G order) = step * ustep (local order) */
 int tc_launch_wvt(tcgpu_ctx *c, double step);
+int tc_launch_wvt_exact(tcgpu_ctx *c, double step);   /* delta in the reference's summation order and roundings */
 int tc_launch_curl(tcgpu_ctx *c, float *l_bfld, int a_in_w);   /* a_in_w: pos4.w / mirror.w hold A (equal components) */
 int tc_launch_find_ngb(tcgpu_ctx *c, int ipart, float hsml);
 void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k);
