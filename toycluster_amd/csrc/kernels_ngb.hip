@@ -1342,6 +1342,8 @@ struct tc_xwvt_args {
     int xshift;         /* added to the query level (tuning: coarser leaves = fewer cells to walk, more candidates to test) */
     int orphans_only;   /* k_wvt_exact: run only when the local set has orphans (k_wvt_exact4 did the launch otherwise) */
     int dbg;            /* profiling only (results invalid): 1 = stop after A1, 2 = no B */
+    const uint32_t *pf; /* cell starts in curve order (tc_launch_pfirst), levels pf_lmin..lmax, entries biased per level */
+    int pf_lmin;
 };
 
 /* periodic distance (one dimension) from x to the cell [c s, (c + 1) s) of a ring of circumference box; 0 inside */
@@ -1608,13 +1610,130 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact(tc_xwvt_args a)
     });
 }
 
-/* The same sweep with FOUR lanes per particle for the two phases that touch memory (the launch's normal kernel; a
- * local set with orphans takes k_wvt_exact above).  A1 runs one lane per particle as above; then, 16 particles at a
+/* A1 on the curve-ordered cell starts (pf, tc_launch_pfirst): no memory is touched while walking.  A node's eight
+ * children are classified at once -- per dimension the periodic distance from the particle to the lower and to the upper
+ * half, nearest and farthest point -- into "overlaps the ball" and "inside the ball" masks, brought into curve order by
+ * a table look-up (perm[orientation][mask]).  Children that are inside the ball, or overlap it at the query level, are
+ * final: their key ranges (level-Lq keys) are noted in curve order, adjacent ones merged; the others are descended into,
+ * one at a time (the node's state waits in a per-lane LDS stack).  Every iteration of the wave's loop is one visit of
+ * one node per lane.  At the end the key ranges become index runs: [pf[a], pf[b + 1]).  Returns the number of runs. */
+__device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint32_t *pf, int pf_lmin, bool valid, float xi,
+                                               float yi, float zi, float hq, int Lq, const uint64_t *inv64,
+                                               const unsigned char *perm, uint32_t *stk, uint2 *runs, int *flags)
+{
+    const float boxf = k.boxsize_f, boxh = k.boxhalf_f;
+    const float hp = (float)((double)hq * (1.0 + 1e-5) + k.boxsize * 4e-6);
+    const float hp2 = hp * hp;
+    const float hin = fmaxf((float)((double)hq * (1.0 - 1e-5) - k.boxsize * 4e-6), 0.0f);
+    const float hin2 = hin * hin;
+    int l = 0;                               /* level of the current node */
+    int cx = 0, cy = 0, cz = 0;              /* its cell coordinates */
+    uint32_t key = 0, st = 0;                /* its key prefix and orientation */
+    uint32_t cov = 0, cfin = 0;              /* children still to do (curve order): overlapping / final among them */
+    bool enter = true, active = valid;
+    uint32_t ra = 0, rb = 0;
+    bool have = false;
+    int nout = 0;
+    auto emit = [&](uint32_t A, uint32_t B) {
+        if (have && A == rb + 1u) rb = B;
+        else {
+            if (have) { if (nout < TC_XRUNCAP) runs[(size_t)nout * 64] = make_uint2(ra, rb); nout++; }
+            ra = A; rb = B; have = true;
+        }
+    };
+    while (tc_ballot(active)) {
+        if (active) {
+            const float s = __builtin_ldexpf(boxf, -(l + 1));          /* edge of the children */
+            if (enter) {
+                /* periodic distance per dimension from the particle to the midpoint of the lower / upper child */
+                const float hs = 0.5f * s;
+                float g[6], f[6];                                    /* nearest / farthest distance, [2 d + half] */
+                /* midpoint of the node = (2 c + 1) s, from the integer coordinates: no drift over pushes and pops */
+                const float xs[3] = {xi, yi, zi}, ms[3] = {(float)(2 * cx + 1) * s, (float)(2 * cy + 1) * s, (float)(2 * cz + 1) * s};
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const float u = xs[d] - ms[d];
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        float dd = fabsf(hf ? u - hs : u + hs);
+                        dd = dd > boxh ? boxf - dd : dd;
+                        g[2 * d + hf] = fmaxf(dd - hs, 0.0f);
+                        f[2 * d + hf] = dd + hs;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++) { g[q] *= g[q]; f[q] *= f[q]; }
+                uint32_t ov = 0, in = 0;                             /* octant o: bit 2 = y half, bit 1 = z half, bit 0 = x half */
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const float g2 = g[o & 1] + g[2 + ((o >> 2) & 1)] + g[4 + ((o >> 1) & 1)];
+                    const float f2 = f[o & 1] + f[2 + ((o >> 2) & 1)] + f[4 + ((o >> 1) & 1)];
+                    ov |= (g2 <= hp2 ? 1u : 0u) << o;
+                    in |= (f2 <= hin2 ? 1u : 0u) << o;
+                }
+                cov = perm[st * 256 + ov];
+                cfin = (l + 1 == Lq) ? cov : (uint32_t)perm[st * 256 + (in & ov)];
+                enter = false;
+            }
+            /* final children ahead of the first one that has to be opened: note their key ranges */
+            const uint32_t part = cov & ~cfin;
+            const uint32_t upto = part ? (1u << __builtin_ctz(part)) - 1u : 0xffu;
+            uint32_t fn = cov & cfin & upto;
+            cov &= ~fn;
+            const int sh = 3 * (Lq - (l + 1));
+            while (fn) {
+                const int a0 = __builtin_ctz(fn);
+                const int len = __builtin_ctz(~(fn >> a0));
+                fn &= ~(((1u << len) - 1u) << a0);
+                const uint32_t A = ((key << 3) + (uint32_t)a0) << sh;
+                const uint32_t B = ((((key << 3) + (uint32_t)(a0 + len - 1)) + 1u) << sh) - 1u;
+                emit(A, B);
+            }
+            if (part) {                                              /* open the next child */
+                const int kk = __builtin_ctz(part);
+                cov &= ~(1u << kk);
+                stk[64 * l] = cov | (cfin << 8) | (st << 16);
+                const uint32_t e = (uint32_t)(inv64[st] >> (8 * kk)) & 0xffu;
+                cx = 2 * cx + (int)(e & 1u);
+                cy = 2 * cy + (int)((e >> 2) & 1u);
+                cz = 2 * cz + (int)((e >> 1) & 1u);
+                key = (key << 3) + (uint32_t)kk;
+                st = e >> 3;
+                l++;
+                enter = true;
+            } else if (l == 0) active = false;
+            else {                                                   /* node done: back to its parent */
+                l--;
+                const uint32_t w = stk[64 * l];
+                key >>= 3;
+                cx >>= 1; cy >>= 1; cz >>= 1;
+                cov = w & 0xffu; cfin = (w >> 8) & 0xffu; st = w >> 16;
+            }
+        }
+    }
+    if (have) { if (nout < TC_XRUNCAP) runs[(size_t)nout * 64] = make_uint2(ra, rb); nout++; }
+    if (nout > TC_XRUNCAP) { atomicOr(&flags[3], 1); nout = TC_XRUNCAP; }
+    /* key ranges -> index runs */
+    uint32_t off = 0;
+    for (int L = pf_lmin; L < Lq; L++) off += (1u << (3 * L)) + 1u;
+    const uint32_t *pfL = pf + off;
+    const uint32_t bias = (uint32_t)(Lq - pf_lmin) * (uint32_t)(k.n + 1);
+    int m = 0;
+    for (int t = 0; t < nout; t++) {
+        const uint2 kr = runs[(size_t)t * 64];
+        const uint32_t f0 = pfL[kr.x] - bias, e0 = pfL[kr.y + 1u] - bias;
+        if (e0 > f0) { runs[(size_t)m * 64] = make_uint2(f0, e0); m++; }
+    }
+    return m;
+}
+
+/* The same sweep with FOUR lanes per particle for the two phases that touch memory (the launch's normal kernel).
+ * A1 runs one lane per particle on the curve-ordered cell starts (ordered_runs_pf); then, 16 particles at a
  * time, a quad walks its particle's runs four candidates per step -- one 64-byte read instead of four scattered ones --
  * keeps the hits' positions (in ascending index: rank inside the step from the quad's lane mask) in LDS, and evaluates
  * buffered hits four at a time; the f32 accumulator then takes the four terms in order, passed through the quad with
  * DPP (the order and every rounding of src/wvt_relax.c:167-169). */
-#define TC_X4CAP 32            /* buffered hit positions per particle */
+#define TC_X4CAP 16            /* buffered hit positions per particle */
 
 __device__ __forceinline__ uint32_t quad_bits(uint64_t ballot, int lane)
 {
@@ -1636,17 +1755,32 @@ __device__ __forceinline__ float quad_bcast(float v, int kk)
 
 __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
 {
-    __shared__ __align__(16) float4 lds_hits4[WPB * 16 * TC_X4CAP];
+    __shared__ __align__(16) float4 lds_hits4[WPB * 16 * TC_X4CAP];       /* A2 / B: hit positions; A1: the per-lane node stack */
     __shared__ int lds_nruns[WPB * 64];
-    __shared__ unsigned char lds_inv[TC_HILBERT_NSTATES * 8];
-    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES * 8; t += TBN) lds_inv[t] = TC_HILBERT_INV[t];
+    __shared__ double lds_terms[WPB * 64 * 3];                             /* B: the terms of a step, [quad][hit][component] */
+    __shared__ uint64_t lds_inv64[TC_HILBERT_NSTATES];                     /* the 8 children of an orientation, one per byte */
+    __shared__ unsigned char lds_perm[TC_HILBERT_NSTATES * 256];           /* octant mask -> curve-order mask */
+    static_assert(16 * TC_X4CAP * sizeof(float4) >= (TC_MAX_LEVEL + 1) * 64 * sizeof(uint32_t), "stack fits the hit buffer");
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES; t += TBN) {
+        uint64_t r = 0;
+        for (int kk = 0; kk < 8; kk++) r |= (uint64_t)TC_HILBERT_INV[t * 8 + kk] << (8 * kk);
+        lds_inv64[t] = r;
+    }
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES * 256; t += TBN) {
+        const int stt = t >> 8, msk = t & 255;
+        uint32_t cm = 0;
+        for (int kk = 0; kk < 8; kk++) cm |= ((msk >> (TC_HILBERT_INV[stt * 8 + kk] & 7)) & 1u) << kk;
+        lds_perm[t] = (unsigned char)cm;
+    }
     __syncthreads();
     const tc_dev_const &k = a.k;
-    if (*k.norph > 0) return;                                   /* k_wvt_exact does this launch */
     const int wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_hits4 + (size_t)wave * 16 * TC_X4CAP);
     const int q = lane >> 2, lq = lane & 3;
     const uint32_t below = (1u << lq) - 1u;
     float4 *buf = lds_hits4 + ((size_t)wave * 16 + q) * TC_X4CAP;
+    double *tq = lds_terms + ((size_t)wave * 16 + q) * 12;          /* this quad's 4 x 3 terms */
+    const int lc = lq < 3 ? lq : 0;                                  /* the component this lane accumulates (lane 3: a copy of x) */
     int *nr = lds_nruns + wave * 64;
     uint2 *wruns = a.runs + (size_t)(blockIdx.x * WPB + wave) * ((size_t)TC_XRUNCAP * 64);
     const double boxinv = k.boxinv;
@@ -1667,9 +1801,9 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
                 tc_particle_levels(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmax, h0, rg, &lmin, &lmaxp);
             }
             const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
-            const tc_level_desc D = k.lvl[Lq];
-            const float hp = (float)((double)hq * (1.0 + 1e-5) + k.boxsize * 4e-6);
-            nr[lane] = ordered_runs(k, valid, pi.x, pi.y, pi.z, hp * hp, Lq, D, lds_inv, wruns + lane, a.flags);
+            wave_lds_fence();                                         /* the stack shares its LDS with the hit buffers */
+            nr[lane] = ordered_runs_pf(k, a.pf, a.pf_lmin, valid, pi.x, pi.y, pi.z, hq, Lq, lds_inv64, lds_perm, stk + lane,
+                                       wruns + lane, a.flags);
         }
         /* the runs were written one lane per particle and are read by the particle's quad */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1692,39 +1826,63 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
             const int nruns = nr[pl];
             const uint2 *pruns = wruns + pl;
             const double step_hi = a.step * (double)pi.w;                   /* step * hsml[ipart], src/wvt_relax.c:167 */
-            int ri = 0, nlist = 0, cnt = 0;
-            uint32_t j = 0, jend = 0;
-            bool cdone = !valid;
-            float d0 = 0, d1 = 0, d2 = 0;
+            int nlist = 0, cnt = 0;
+            float dacc = 0;                                              /* delta[lc] of this quad's particle */
+            /* no neighbour of an interior particle lies beyond half a box in any coordinate: the folding of
+             * src/wvt_relax.c:148-154 cannot fire for any quad of this wave */
+            const double ext = (double)hq * (1.0 + 1e-5) + k.boxsize * 1e-5;
+            const bool wrap = tc_ballot(valid && !((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
+                                                   && (double)yi <= k.boxsize - ext && (double)zi >= ext && (double)zi <= k.boxsize - ext)) != 0;
+            /* Candidate stream with its loads one step ahead: the four positions of the NEXT step and the run after
+             * the next are requested before the current step's positions are looked at, so a step never waits for a
+             * load it has just issued.  (j, jend): the current run; (nj, njend): the next one; ri: runs fetched. */
+            bool cdone = !valid || nruns == 0;
+            uint32_t j = 0, jend = 0, nj = 0, njend = 0;
+            int ri = 0;
+            if (!cdone) {
+                const uint2 r0 = pruns[0];
+                j = r0.x; jend = r0.y;
+                ri = 1;
+                if (nruns > 1) { const uint2 r1 = pruns[64]; nj = r1.x; njend = r1.y; ri = 2; }
+            }
+            float4 pc = k.pos4[(!cdone && j + (uint32_t)lq < jend) ? j + (uint32_t)lq : (uint32_t)i];
             for (;;) {
                 while (!tc_ballot(cnt > TC_X4CAP - 4) && tc_ballot(!cdone)) {
-                    if (!cdone && j >= jend) {
-                        if (ri < nruns) {
-                            const uint2 r = pruns[(size_t)ri * 64];
-                            ri++;
-                            j = r.x; jend = r.y;
-                        } else cdone = true;
-                    }
                     const uint32_t jc = j + (uint32_t)lq;
                     const bool act = !cdone && jc < jend;
-                    const float4 p = k.pos4[act ? jc : (uint32_t)i];
-                    const float r2 = tc_ngb_r2(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f);
+                    /* where the next step reads */
+                    uint32_t j2 = j + 4u, jend2 = jend;
+                    const bool adv = !cdone && j2 >= jend;
+                    bool last = false;
+                    if (adv) {
+                        last = njend == 0u;                              /* no run left */
+                        j2 = nj; jend2 = njend;
+                    }
+                    const uint32_t jn = j2 + (uint32_t)lq;
+                    const float4 pn = k.pos4[(!cdone && !last && jn < jend2) ? jn : (uint32_t)i];
+                    if (adv) {
+                        nj = njend = 0u;
+                        if (ri < nruns) { const uint2 r = pruns[(size_t)ri * 64]; ri++; nj = r.x; njend = r.y; }
+                    }
+                    const float r2 = tc_ngb_r2(xi, yi, zi, pc.x, pc.y, pc.z, k.boxhalf_f, k.boxsize_f);
                     const bool hit = act && r2 < hq2;
                     const uint32_t mh = quad_bits(tc_ballot(hit), lane);
                     /* the reference's list ends at its NGBMAX-th entry (src/tree.c:91-92); the particle itself is on the
                      * list but not in the sum (src/wvt_relax.c:141-142) */
                     const bool keep = hit && nlist + (int)__popc(mh & below) < TC_NGBMAX && jc != (uint32_t)i;
                     const uint32_t mk = quad_bits(tc_ballot(keep), lane);
-                    if (keep) buf[cnt + (int)__popc(mk & below)] = p;
+                    if (keep) buf[cnt + (int)__popc(mk & below)] = pc;
                     cnt += (int)__popc(mk);
                     nlist += (int)__popc(mh);
                     if (!cdone) {
-                        j += 4;
+                        j = j2; jend = jend2;
+                        if (last) cdone = true;
                         if (nlist >= TC_NGBMAX) {
                             cdone = true;
                             if (lq == 0) atomicAdd(&a.flags[4], 1);
                         }
                     }
+                    pc = pn;
                 }
                 wave_lds_fence();
                 if (a.dbg & 2) cnt = 0;
@@ -1734,12 +1892,14 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
                     float dx = (float)((double)(xi - pj.x) * boxinv);
                     float dy = (float)((double)(yi - pj.y) * boxinv);
                     float dz = (float)((double)(zi - pj.z) * boxinv);
-                    dx = dx > 0.5f ? dx - 1.0f : dx;                    /* src/wvt_relax.c:148-154 (0.5 is exact in f32) */
-                    dy = dy > 0.5f ? dy - 1.0f : dy;
-                    dz = dz > 0.5f ? dz - 1.0f : dz;
-                    dx = dx < -0.5f ? dx + 1.0f : dx;
-                    dy = dy < -0.5f ? dy + 1.0f : dy;
-                    dz = dz < -0.5f ? dz + 1.0f : dz;
+                    if (wrap) {                                         /* wave-uniform */
+                        dx = dx > 0.5f ? dx - 1.0f : dx;                /* src/wvt_relax.c:148-154 (0.5 is exact in f32) */
+                        dy = dy > 0.5f ? dy - 1.0f : dy;
+                        dz = dz > 0.5f ? dz - 1.0f : dz;
+                        dx = dx < -0.5f ? dx + 1.0f : dx;
+                        dy = dy < -0.5f ? dy + 1.0f : dy;
+                        dz = dz < -0.5f ? dz + 1.0f : dz;
+                    }
                     const float r2 = dx * dx + dy * dy + dz * dz;
                     const float h = (float)(0.5 * (double)(pi.w + pj.w));
                     const bool in = ok && !(r2 > h * h);
@@ -1776,24 +1936,20 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
                             e2 = step_hi * (double)wk * (double)dz / (double)r;
                         }
                     }
-                    /* src/wvt_relax.c:167-169: the f32 accumulator takes the four terms in order, rounded after each
-                     * (a lane without a term adds 0.0, which changes nothing) */
+                    /* src/wvt_relax.c:167-169: the f32 accumulators take the four terms in order, rounded after each (a
+                     * lane without a term contributes 0.0, which changes nothing).  The quad's 4 x 3 terms are transposed
+                     * through LDS: lane c then owns component c and adds the four hits' terms one after the other. */
+                    tq[3 * lq] = e0; tq[3 * lq + 1] = e1; tq[3 * lq + 2] = e2;
+                    wave_lds_fence();
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const float n0 = (float)((double)d0 + e0), n1 = (float)((double)d1 + e1), n2 = (float)((double)d2 + e2);
-                        d0 = quad_bcast(n0, kk); d1 = quad_bcast(n1, kk); d2 = quad_bcast(n2, kk);
-                    }
+                    for (int kk = 0; kk < 4; kk++) dacc = (float)((double)dacc + tq[3 * kk + lc]);
+                    wave_lds_fence();
                 }
                 cnt = 0;
                 wave_lds_fence();
                 if (!tc_ballot(!cdone)) break;
             }
-            if (valid && lq == 0) {
-                const size_t g = a.lg[i];
-                a.delta[3 * g] = d0;
-                a.delta[3 * g + 1] = d1;
-                a.delta[3 * g + 2] = d2;
-            }
+            if (valid && lq < 3) a.delta[3 * (size_t)a.lg[i] + lq] = dacc;
         }
     });
 }
@@ -1834,17 +1990,15 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
         c->xruns_bytes = want;
     }
     a.runs = (uint2 *)c->xruns;
+    a.pf = c->pf;
+    a.pf_lmin = c->pf_lmin;
+    a.orphans_only = 0;
     tc_phase_begin(c, PH_WVT);
-    /* option "xsweep_kernel" = 1 (tests): the one-lane-per-particle kernel for every launch; by default it only runs
-     * when the local set has orphans (a device-side count: both kernels are launched, one returns at once) */
-    if (!c->xsweep_kernel) {
-        TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
-        a.orphans_only = 1;
-        k_wvt_exact4<<<g4, TBN, 0, c->stream>>>(a);
-    }
-    a.orphans_only = !c->xsweep_kernel;
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
-    k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
+    /* option "xsweep_kernel" = 1 (tests): the one-lane-per-particle kernel on the (x, y, z) cell table -- an independent
+     * second implementation of the same sums */
+    if (c->xsweep_kernel) k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
+    else k_wvt_exact4<<<g4, TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
