@@ -96,6 +96,19 @@ def reversed_peano_key(x, y, z):
     return (hi.value << 64) | lo.value
 
 
+DEV_SWEEP_ROUND_ONCE, DEV_TREE_SUMS, DEV_POW_ULP, DEV_KERNEL_ULP, DEV_EXACT_BALL = 1, 2, 4, 8, 16
+
+
+def set_deviation(mask=0):
+    """Attribution experiments (tc_oracle.h ORC_DEV_*): 0 = the faithful restatement.  Process-wide; reset after use.
+    DEV_EXACT_BALL answers every ball query as the reference's brute-force Find_ngb_simple would (its tree search misses
+    the particles of the occasional mis-placed node)."""
+    L = lib()
+    L.orc_set_deviation.argtypes = [C.c_int]
+    L.orc_set_deviation.restype = None
+    L.orc_set_deviation(int(mask))
+
+
 def set_double_beta(rho0_fac=0.0, rc_fac=0.0):
     """The reference's -DDOUBLE_BETA_COOL_CORES build as a process-wide switch of the oracle (Param.Rho0_Fac,
     Param.Rc_Fac; both 0 = the default build).  Reset it after use."""

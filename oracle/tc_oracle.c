@@ -81,6 +81,9 @@ struct orc_state {
     /* stats */
     double st_queries, st_iters, st_pairs;
     long st_trunc_density, st_trunc_sweep;   /* queries that filled the NGBMAX list (tree.c:91-92) */
+    /* ORC_DEV_EXACT_BALL only: a uniform grid over the positions the tree was built on */
+    int gdim;
+    int32_t *gstart, *gitem;
 };
 
 /* ---------------------------------------------------------------- life cycle */
@@ -116,6 +119,7 @@ void orc_destroy(orc_state *s)
     if (!s) return;
     free(s->halo); free(s->pos); free(s->id); free(s->hsml); free(s->rho); free(s->vhf);
     free(s->rhom); free(s->apot); free(s->bfld); free(s->tparent); free(s->key); free(s->tree);
+    free(s->gstart); free(s->gitem);
     free(s);
 }
 
@@ -341,6 +345,86 @@ static int new_node(orc_state *s, int ipart, int parent, u128 key, int lvl)
     return node;
 }
 
+/* ORC_DEV_EXACT_BALL (attribution experiment, NOT reference behaviour): the ball query as the reference's own brute-force
+ * twin Find_ngb_simple (wvt_relax.c:296-340) answers it -- every particle passing the f32 predicate of tree.c:67-89, in
+ * ascending index, the list cut at NGBMAX -- found through a uniform grid instead of an O(N) scan.  The reference's
+ * tree search is NOT always that set: Build_Tree now and then creates a node under a parent of the wrong level
+ * (tree.c:201-226 collapses leaves, the next particle's walk then steps into stale or unrelated nodes), the node's
+ * centre (tree.c:297-306) is then cells away from its particles and ball queries that should reach them pass it by. */
+static void build_grid(orc_state *s)
+{
+    const int n = s->n;
+    int g = (int)cbrt(n / 4.0);
+    if (g < 1) g = 1;
+    if (g > 128) g = 128;
+    s->gdim = g;
+    free(s->gstart); free(s->gitem);
+    s->gstart = calloc((size_t)g * g * g + 1, sizeof(int32_t));
+    s->gitem = malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+    int32_t *cell = malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+    for (int i = 0; i < n; i++) {
+        int c[3];
+        for (int d = 0; d < 3; d++) {
+            c[d] = (int)((double)s->pos[3 * i + d] / s->box * g);
+            if (c[d] >= g) c[d] = g - 1;
+            if (c[d] < 0) c[d] = 0;
+        }
+        cell[i] = (c[0] * g + c[1]) * g + c[2];
+        s->gstart[cell[i] + 1]++;
+    }
+    for (int q = 0; q < g * g * g; q++) s->gstart[q + 1] += s->gstart[q];
+    int32_t *fill = calloc((size_t)g * g * g, sizeof(int32_t));
+    for (int i = 0; i < n; i++) s->gitem[s->gstart[cell[i]] + fill[cell[i]]++] = i;   /* ascending inside a cell */
+    free(fill); free(cell);
+}
+
+static int cmp_i32(const void *a, const void *b)
+{
+    const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+static int find_ngb_grid(const orc_state *s, int ipart, float hsml, int32_t *ngblist)
+{
+    const float boxsize = s->box, boxhalf = s->box * 0.5;
+    const float xi = s->pos[3 * ipart], yi = s->pos[3 * ipart + 1], zi = s->pos[3 * ipart + 2];
+    const int g = s->gdim;
+    const double cs = s->box / g;
+    const double hp = (double)hsml * (1 + 1e-5) + s->box * 1e-5;
+    int lo[3], cnt[3];
+    const float xs[3] = {xi, yi, zi};
+    for (int d = 0; d < 3; d++) {
+        lo[d] = (int)floor((xs[d] - hp) / cs);
+        int hi = (int)floor((xs[d] + hp) / cs);
+        cnt[d] = hi - lo[d] + 1;
+        if (cnt[d] >= g) { lo[d] = 0; cnt[d] = g; }
+    }
+    int cap = 4096, m = 0;
+    int32_t *tmp = malloc((size_t)cap * sizeof(int32_t));
+    for (int a = 0; a < cnt[0]; a++)
+        for (int b = 0; b < cnt[1]; b++)
+            for (int c = 0; c < cnt[2]; c++) {
+                const int cx = ((lo[0] + a) % g + g) % g, cy = ((lo[1] + b) % g + g) % g, cz = ((lo[2] + c) % g + g) % g;
+                const int q = (cx * g + cy) * g + cz;
+                for (int t = s->gstart[q]; t < s->gstart[q + 1]; t++) {
+                    const int j = s->gitem[t];
+                    float dx = fabs(xi - s->pos[3 * j]), dy = fabs(yi - s->pos[3 * j + 1]), dz = fabs(zi - s->pos[3 * j + 2]);
+                    if (dx > boxhalf) dx -= boxsize;
+                    if (dy > boxhalf) dy -= boxsize;
+                    if (dz > boxhalf) dz -= boxsize;
+                    if (dx * dx + dy * dy + dz * dz < hsml * hsml) {
+                        if (m == cap) { cap *= 2; tmp = realloc(tmp, (size_t)cap * sizeof(int32_t)); }
+                        tmp[m++] = j;
+                    }
+                }
+            }
+    qsort(tmp, m, sizeof(int32_t), cmp_i32);
+    if (m > ORC_NGBMAX) m = ORC_NGBMAX;
+    memcpy(ngblist, tmp, (size_t)m * sizeof(int32_t));
+    free(tmp);
+    return m;
+}
+
 /* tree.c:124-271 */
 int orc_build_tree(orc_state *s)
 {
@@ -435,6 +519,7 @@ int orc_build_tree(orc_state *s)
             lowest = lvl;
         }
     }
+    if (orc_dev & ORC_DEV_EXACT_BALL) build_grid(s);
     return s->nnodes;
 }
 
@@ -457,6 +542,7 @@ int orc_tree_nodes(const orc_state *s, uint32_t *bitfield, int32_t *dnext, float
 /* tree.c:25-111 -- all arithmetic in f32 as in the reference */
 int orc_find_ngb_tree(const orc_state *s, int ipart, float hsml, int32_t *ngblist)
 {
+    if ((orc_dev & ORC_DEV_EXACT_BALL) && s->gstart) return find_ngb_grid(s, ipart, hsml, ngblist);
     const float boxsize = s->box;
     const float boxhalf = s->box * 0.5;
     const float xi = s->pos[3 * ipart], yi = s->pos[3 * ipart + 1], zi = s->pos[3 * ipart + 2];

@@ -119,6 +119,8 @@ int orc_reassign_to_halos(int n, const float *pos, double boxsize, int nhalos, c
 #define ORC_DEV_TREE_SUMS        2   /* Find_hsml's three f64 sums as 64 partial sums + a reduction tree */
 #define ORC_DEV_POW_ULP          4   /* every pow() result moved by -1/0/+1 f64 ulp */
 #define ORC_DEV_KERNEL_ULP       8   /* W and W' moved by -1/0/+1 f64 ulp before their f32 rounding */
+#define ORC_DEV_EXACT_BALL      16   /* every ball query answered as Find_ngb_simple (wvt_relax.c:296-340) would: the reference's
+                                      * tree search misses neighbours stored under a mis-placed node (tc_oracle.c, find_ngb_grid) */
 void orc_set_deviation(int mask);
 /* number of ball queries that filled the NGBMAX list (tree.c:91-92) since the last reset */
 void orc_truncations(orc_state *s, long *density, long *sweep, int reset);

@@ -1,10 +1,14 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C ABI of
 libtcgpu.so (toycluster_amd.binding -> include/tcgpu.h); the oracle is only the checker.
 
-Parity tiers:
-  T0 bit-exact : Peano keys, sort permutation / ids, iteration count, step schedule
+Parity tiers (DESIGN.md section 2 for what round 3 changed):
+  T0 bit-exact : Peano keys, sort permutation / ids, iteration count, step schedule -- and, since round 3, the WVT
+                 displacement and therefore the POSITIONS after any number of iterations (the sweep reproduces the
+                 reference's per-neighbour f32 accumulation in ascending index, src/wvt_relax.c:167-169)
   T1 set-exact : neighbour sets for identical f32 inputs
-  T2 tolerance : |dpos| <= 1e-3 hsml, |drho|/rho <= 1e-3, |dhsml|/hsml <= 1e-3, errMean to 5 digits
+  T2 tolerance : |drho|/rho <= 1e-3, |dhsml|/hsml <= 1e-3 (observed: the solver's own +-0.05/295 band, <= 2e-4 / 6e-4,
+                 when a carried hsml differs in its last bit and a raw-count guard of src/sph.c:49-54 goes the other
+                 way), errMean to 5 digits
 The only differences expected from the oracle are f64 summation order (1e-16 relative) and the
 device libm's pow() (<= 1 ulp f64), so single-pass results are compared far tighter than T2.
 """
@@ -437,10 +441,28 @@ def test_wvt_sweep_single_step(gpu, golden_case):
     gpu.upload(c["pos"], c["ids"])
     gpu.Find_sph_quantities()
     hs, de = gpu.wvt_step(0.0085, move=False)
-    assert rel(hs, c["w_hsml"]).max() < 3e-7
+    # the reference's order and roundings (f32 accumulator, one rounding per neighbour, ascending index): bit for bit
+    assert np.array_equal(hs, c["w_hsml"])
+    assert np.array_equal(de, c["w_delta"])
+
+
+def test_wvt_sweep_second_implementation_and_f64_mode(golden_case):
+    """The one-lane-per-particle kernel on the (x, y, z) cell table (option xsweep_kernel = 1) is an independent second
+    implementation of the exact sweep: same bits.  Round 2's sweep (option sweep = 1: f64 sums over 64 lanes, rounded
+    once) stays available and stays within 2e-6 of the scale -- the deviation that owned round 2's parity tail."""
+    c = golden_case
     scale = np.abs(c["w_delta"]).max()
-    # reference accumulates in f32 (one rounding per neighbour); we round once: <= ~1e-6 of the scale
-    assert np.abs(de - c["w_delta"]).max() < 2e-6 * scale
+    for opts, exact in (({"xsweep_kernel": 1}, True), ({"sweep": 1}, False), ({"sweep": 1, "fuse": 0}, False)):
+        g = binding.TcGpu(0, options=opts)
+        g.set_model(c["model"]); g.upload(c["pos"], c["ids"])
+        g.Find_sph_quantities()
+        if not exact: g.density_error()                     # warm pass: the fused kernel sums the sweep on the way
+        hs, de = g.wvt_step(0.0085, move=False)
+        g.close()
+        if exact:
+            assert np.array_equal(de, c["w_delta"])
+        else:
+            assert rel(hs, c["w_hsml"]).max() < 3e-7 and np.abs(de - c["w_delta"]).max() < 2e-6 * scale
 
 
 def test_relaxation_short(gpu, golden_case):
@@ -456,7 +478,7 @@ def test_relaxation_short(gpu, golden_case):
         assert l["err_max"] == pytest.approx(w[1], rel=1e-3)
     p = gpu.particles()
     assert np.array_equal(p["id"], c["r_ids"])
-    assert (np.abs(p["pos"] - c["r_pos"]).max(axis=1) / c["r_hsml"]).max() < TOL_POS
+    assert np.array_equal(p["pos"], c["r_pos"])                      # T0 since round 3
     assert rel(p["hsml"], c["r_hsml"]).max() < TOL_HSML and rel(p["rho"], c["r_rho"]).max() < TOL_RHO
 
 
@@ -477,9 +499,61 @@ def test_relaxation_to_convergence_matches_oracle(gpu):
         assert a["err_mean"] == pytest.approx(b["err_mean"], rel=1e-5)
     p, q = gpu.particles(), o.particles()
     assert np.array_equal(p["id"], q["id"])
-    dpos = np.abs(p["pos"] - q["pos"]).max(axis=1) / q["hsml"]
-    assert dpos.max() < TOL_POS and dpos.mean() < 1e-5
+    assert np.array_equal(p["pos"], q["pos"])                        # T0 since round 3
     assert rel(p["hsml"], q["hsml"]).max() < TOL_HSML and rel(p["rho"], q["rho"]).max() < TOL_RHO
+
+
+FUZZ_CASES = [(3, 16), (101, 74), (101, 129), (3, 4), (11, 40), (101, 30)]
+
+
+@pytest.mark.parametrize("seed,want", FUZZ_CASES)
+def test_fuzz_cases_of_round_2(gpu, seed, want):
+    """Fixed cases of tools/fuzz_oracle.py, first of all the three that FAILED at the end of round 2 (seed 3 case 16:
+    positions off by 6.8e-3 hsml; seed 101 case 74: curl 3.1e-4; seed 101 case 129: hsml 2.2e-3), then the worst cases
+    of the CPU-only attribution run (tools/attribute_tail.py, profiles/round3_parity_tail_attribution.json).  That run
+    reproduced those very numbers with ONE deviation injected into the oracle -- the sweep rounded once instead of after
+    every neighbour -- and zeros for the other three.  With the sweep exact, the positions are equal bit for bit and
+    hsml / rho / curl agree to a few f32 ulp -- against the algorithm with exact ball queries (a).  Against the
+    faithful tree search (b) a second, unrelated effect remains: the reference's tree misses neighbours near a mis-placed
+    node.  Small N on purpose: hundreds of NGBMAX-truncated lists per case (src/tree.c:91-92), the discontinuity that
+    turned 1e-6 into 7e-3."""
+    rng = np.random.default_rng(seed)
+    for case in range(want + 1):
+        n = int(rng.integers(2000, 26000)); iters = int(rng.integers(1, 5))
+        name = "merger" if rng.random() < 0.7 else "single"
+        m = M.preset(name, n)
+        if rng.random() < 0.3:
+            m = M.with_subhalos(m, int(rng.integers(2, 7)), n, seed=int(rng.integers(1, 100)))
+        pos, ids = M.sample_gas(m, n, seed=int(rng.integers(1, 10**6)))
+    gpu.set_model(m); gpu.upload(pos, ids)
+    lg = gpu.Regularise_sph_particles(max_iter=iters); gpu.Find_sph_quantities(); pg = gpu.particles()
+    # (a) against the oracle with every ball query answered exactly (the reference's Find_ngb_simple, wvt_relax.c:296-340)
+    O.set_deviation(O.DEV_EXACT_BALL)
+    try:
+        o = O.Oracle(m, pos, ids)
+        lo = o.regularise(max_iter=iters); o.find_sph_quantities(); po = o.particles()
+        a = ((po["rho_model"].astype(np.float64) / po["rho_model"].max()) ** 0.5).astype(np.float32)
+        apot = np.stack([a, a, a], axis=1)
+        o.set_apot(apot); bo = o.bfld_from_rotA()
+    finally:
+        O.set_deviation(0)
+    assert len(lg) == len(lo)
+    for x, y in zip(lg, lo):
+        assert x["step"] == y["step"] and x["err_mean"] == pytest.approx(y["err_mean"], rel=1e-6)
+    assert np.array_equal(pg["id"], po["id"])
+    assert np.array_equal(pg["pos"], po["pos"])
+    assert rel(pg["hsml"], po["hsml"]).max() < 2e-6 and rel(pg["rho"], po["rho"]).max() < 2e-6
+    assert np.median(rel(pg["rho"], po["rho"])) == 0
+    bg = gpu.Bfld_from_rotA_SPH(apot)
+    assert np.abs(bg - bo).max() < 1e-5 * np.abs(bo).max()
+    # (b) against the faithful restatement, tree search and all: the same, but for the neighbourhood of the occasional
+    # node that Build_Tree puts under a parent of the wrong level (tree.c:201-226, :297-306; ~1e-5 of the leaves): its
+    # particles are missed by queries that should find them.  Not reproduced (DESIGN.md section 5).
+    o = O.Oracle(m, pos, ids)
+    o.regularise(max_iter=iters); o.find_sph_quantities(); pf = o.particles()
+    assert np.array_equal(pg["id"], pf["id"])
+    dp = np.abs(pg["pos"] - pf["pos"]).max(axis=1) / pf["hsml"]
+    assert dp.max() < TOL_POS and (dp > 0).mean() < 0.15
 
 
 def test_config1_full_relaxation(gpu):
@@ -727,9 +801,8 @@ def test_ngbmax_overflow_paths(gpu):
     p1 = gpu.particles()
     assert np.array_equal(p1["id"], q1["id"])
     assert rel(p1["hsml"], q1["hsml"]).max() < 1e-6 and rel(p1["rho"], q1["rho"]).max() < 1e-6
-    hs, de = gpu.wvt_step(0.0085, move=False)                   # plain sweep kernel (k_wvt)
-    scale = np.abs(ode).max()
-    assert rel(hs, ohs).max() < 3e-7 and np.abs(de - ode).max() < 2e-6 * scale
+    hs, de = gpu.wvt_step(0.0085, move=False)                   # the exact sweep: truncated lists and all
+    assert np.array_equal(hs, ohs) and np.array_equal(de, ode)
 
     o.find_sph_quantities()                                     # warm pass
     q2 = o.particles()
@@ -738,7 +811,12 @@ def test_ngbmax_overflow_paths(gpu):
     p2 = gpu.particles()
     assert rel(p2["hsml"], q2["hsml"]).max() < 1e-6 and rel(p2["rho"], q2["rho"]).max() < 1e-6
     hs2, de2 = gpu.wvt_step(0.0085, move=False)
-    assert rel(hs2, ohs2).max() < 3e-7 and np.abs(de2 - ode2).max() < 2e-6 * np.abs(ode2).max()
+    assert np.array_equal(hs2, ohs2) and np.array_equal(de2, ode2)
+    g1 = binding.TcGpu(0, options={"sweep": 1})                 # round 2's sweep: the index-threshold bisection of k_wvt / wvt_sum
+    g1.set_model(m); g1.upload(pos, ids); g1.Find_sph_quantities(); g1.density_error()
+    hs3, de3 = g1.wvt_step(0.0085, move=False)
+    g1.close()
+    assert rel(hs3, ohs2).max() < 3e-7 and np.abs(de3 - ode2).max() < 2e-6 * np.abs(ode2).max()
 
 
 def test_particles_on_the_box_faces(gpu):

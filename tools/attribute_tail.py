@@ -22,6 +22,7 @@ DEVS = [("sweep rounded once (f64 sum, unit step)", 1, False),
         ("pow() +-1 f64 ulp", 4, False),
         ("W, W' +-1 f64 ulp before f32 rounding", 8, False),
         ("all four arithmetic deviations", 15, False),
+        ("tree search -> exact ball query (Find_ngb_simple's answer)", 16, False),
         ("input positions +-1 f32 ulp (BASELINE.md s2 probe)", 0, True)]
 
 
