@@ -13,9 +13,11 @@ Weak scaling: 2e6 particles per GPU; every rank solves its contiguous Peano rang
 exchange positions / smoothing lengths with RCCL all-gathers each iteration.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     -- dominant kernel (k_iter = fused density solve + WVT sweep): algorithmic bytes /
-                  measured kernel time vs HBM peak (the kernel is VALU-bound)
-  cpu_baseline -- the CPU oracle ("port" of the reference algorithm, OpenMP) on a bounded sample
+  roofline     -- dominant kernel (k_iter = hsml / density solve): counted vector flops / measured kernel time vs the
+                  f64 vector peak (the kernel is VALU-bound), HBM figure beside it; the second
+                  kernel of the step (k_wvt_exact4, the sweep in the reference's summation order) in `sweep_kernel`
+  cpu_baseline -- the CPU oracle ("port" of the reference algorithm, OpenMP) on the SAME workload and state:
+                  warm WVT iterations started from the GPU's positions and smoothing lengths
 """
 import argparse
 import json
@@ -35,7 +37,8 @@ F64_VECTOR_PEAK_TFLOPS = 78.6    # MI355X vector f64 peak (half the 157.3 TF f32
 # sweep ~350 pairs x ~40 flop = 14 kflop.  The number of solver visits is COUNTED by a stats pass of this run.
 FLOP_PER_SOLVER_PAIR = 60.0
 FLOP_SWEEP_PER_PARTICLE = 14.0e3
-BYTES_DENSITY_PER_PARTICLE = 56  # K5 (12+4 R, 12 W) + K9 (12+4 R, 12 W), fused in k_iter
+BYTES_DENSITY_PER_PARTICLE = 28  # K5 (12+4 R, 12 W)
+BYTES_SWEEP_PER_PARTICLE = 28    # K9 (12+4 R, 12 W)
 BYTES_ITER_PER_PARTICLE = 868    # whole iteration incl. 128-bit radix sort
 PER_GPU_PARTICLES = 2_000_000
 
@@ -52,9 +55,10 @@ def workload(n_gas):
     return hostio.setup_to_model(s), pos, ids
 
 
-def cpu_baseline(nsample, iters):
-    """Time the oracle (CPU restatement, OpenMP) on a bounded sample of the same workload."""
-    from toycluster_amd import model as M
+def cpu_baseline(m, state, iters):
+    """Time the oracle (CPU restatement, OpenMP) on the benchmark's own workload: `iters` warm WVT iterations started
+    from the state the GPU left behind (positions, ids, carried smoothing lengths), i.e. the same kind of iteration
+    the GPU figure is about (no 2e5 sample any more)."""
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0))
     try:                                          # container CPU share (cgroup v2), e.g. "1600000 100000"
@@ -63,16 +67,15 @@ def cpu_baseline(nsample, iters):
             cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
-    m, pos, ids = workload(nsample)
-    o = O.Oracle(m, pos, ids, nthreads=cores)
-    o.find_sph_quantities()                       # warm-up pass: the timed iterations start warm
+    n = len(state["id"])
+    o = O.Oracle(m, state["pos"], state["id"], hsml=state["hsml"], nthreads=cores)
     t0 = time.time()
-    o.regularise(max_iter=iters - 1)
+    o.regularise(max_iter=iters - 1)              # `iters` loop bodies: sort, tree, density solve, error, sweep, move
     dt = time.time() - t0
-    return {"value": nsample * iters / dt, "unit": "particle-iterations/s", "cores": cores, "kind": "port",
-            "sample_particles": nsample, "sample_iterations": iters, "sample_seconds": dt,
-            "sample": "oracle/tc_oracle.c (OpenMP restatement of the reference path), 2-cluster merger, "
-                      "%d particles, %d warm WVT iterations, %.1f s" % (nsample, iters, dt)}
+    return {"value": n * iters / dt, "unit": "particle-iterations/s", "cores": cores, "kind": "port",
+            "sample_particles": n, "sample_iterations": iters, "sample_seconds": dt,
+            "sample": "oracle/tc_oracle.c (OpenMP restatement of the reference path) on the benchmark's own particles: "
+                      "%d particles, %d warm WVT iterations from the GPU's state, %.1f s" % (n, iters, dt)}
 
 
 def main():
@@ -84,8 +87,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-relax", action="store_true",
                     help="profiling runs: skip the stats pass and the whole-relaxation run behind the timed steps")
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--sweep", type=int, default=0,
+                    help="0: the sweep in the reference's summation order (default, what the library does); 1: round 2's "
+                         "fused f64 sweep (faster, ~1e-6 |delta| off per iteration) -- for A/B runs only")
     ap.add_argument("--force-comm", action="store_true",
                     help="testing: run the RCCL collectives through a 1-rank communicator")
     ap.add_argument("--force-dist", action="store_true",
@@ -118,8 +123,10 @@ def main():
     n_total = args.particles_per_gpu * world
     m, pos, ids = workload(n_total)                          # deterministic => the same particles on every rank
 
-    g = binding.TcGpu(local_rank, rank=rank, nranks=world, unique_id=uid,
-                      options={"force_comm": 1} if args.force_comm else None)
+    opts = {}
+    if args.force_comm: opts["force_comm"] = 1
+    if args.sweep: opts["sweep"] = 1
+    g = binding.TcGpu(local_rank, rank=rank, nranks=world, unique_id=uid, options=opts or None)
     g.set_model(m)
     g.upload(pos, ids)
 
@@ -143,9 +150,9 @@ def main():
         one_step()
     for _ in range(args.warmup):
         one_step()
-    g.phase_times(reset=True)
     g.comm_bytes(reset=True)
 
+    # The timed region runs the library as shipped: per-phase event records OFF (option "timing" = 0, the product default).
     barrier()
     t0 = time.perf_counter()
     errs = [one_step() for _ in range(args.steps)]
@@ -156,14 +163,23 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    phases = g.phase_times()
     recv_bytes = g.comm_bytes() / max(1, args.steps)
     lset = g.local_set_info()
+
+    # Kernel times: the same K steps once more with HIP events around every phase on the library's stream (not timed
+    # by the wall clock above).
+    g.phase_times(reset=True)                                # switches "timing" on
+    for _ in range(args.steps):
+        one_step()
+    phases = g.phase_times()
+    g.set_option("timing", 0)
     dens_s, dens_launch = phases["density"]
     dens_avg = dens_s / max(1, dens_launch)
+    sw_s, sw_launch = phases.get("wvt_sweep", (0.0, 0))
+    sw_avg = sw_s / max(1, sw_launch)
     n_local = (n_total + world - 1) // world
     achieved = BYTES_DENSITY_PER_PARTICLE * n_local / dens_avg / 1e9 if dens_avg > 0 else 0.0
+    state = g.particles() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     # Work counters of one density pass (stats instantiation of the same kernel, outside the timed region):
     # list entries visited by the hsml solver per particle -> counted flops of the launch.
@@ -173,8 +189,9 @@ def main():
         g.density_error()
         st = g.density_stats()
         g.set_option("stats", 0)
-    flop_per_particle = st["pair_evals"] * FLOP_PER_SOLVER_PAIR + FLOP_SWEEP_PER_PARTICLE
+    flop_per_particle = st["pair_evals"] * FLOP_PER_SOLVER_PAIR + (FLOP_SWEEP_PER_PARTICLE if args.sweep else 0.0)
     tflops = flop_per_particle * n_local / dens_avg / 1e12 if dens_avg > 0 else 0.0
+    sweep_tflops = FLOP_SWEEP_PER_PARTICLE * n_local / sw_avg / 1e12 if (sw_avg > 0 and not args.sweep) else 0.0
 
     # One whole relaxation under the reference's stop rule (wvt_relax.c:94-98) from the same initial positions:
     # the second half of BASELINE.json's metric ("iterations to <1% rho-error" = stop-rule count).
@@ -203,10 +220,23 @@ def main():
         except Exception:
             prof = None
 
+    # every rank's view of the step, for the driver's 1 -> 8 curve (rank 0 prints them)
+    mine = {"rank": rank, "phase_ms_per_step": {k: 1e3 * v[0] / args.steps for k, v in phases.items() if v[1]},
+            "recv_bytes_per_step": recv_bytes, "local_set": lset["nloc"], "own": lset["nown"],
+            "local_set_over_own": lset["nloc"] / max(1, lset["nown"]), "passes_repeated": lset["retries"]}
+    per_rank = [mine]
+    if use_dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.cpu_sample, args.cpu_iters)
+            if state is None:                                # sharded run: the baseline is quoted on one GPU's share
+                cpu = {"value": None, "unit": "particle-iterations/s", "cores": None, "kind": "port",
+                       "sample": "not run at N > 1 (the N = 1 line carries it)"}
+            else:
+                cpu = cpu_baseline(m, state, args.cpu_iters)
         value = n_total * args.steps / dt
         out = {
             "metric": "WVT-relaxed particles/sec (whole node) + iterations to <1% rho-error",
@@ -229,22 +259,31 @@ def main():
                                       "sort / cell table / mirror; per iteration the ghost exchange over RCCL (interest pyramids "
                                       "all-gathered, 20 B per ghost sent to the ranks that need it) and two exact scalar "
                                       "all-reduces" % world,
-                       "rank0_local_set": lset, "rank0_recv_bytes_per_step": recv_bytes,
+                       "sweep": ("reference order and roundings (k_wvt_exact4)" if not args.sweep else "round 2's fused f64 sweep (option sweep = 1)"),
+                       "ranks": per_rank,
                        "err_mean_last": errs[-1][0], "err_max_last": errs[-1][1]},
             # k_iter is a gather/stencil kernel bound by the vector ALU, not by HBM: the
             # headline fraction is counted vector flops against the f64 vector peak; the HBM fraction of its
             # compulsory 56 B/particle is reported beside it.
-            "roofline": {"bound": "valu", "kernel": "k_iter (fused density solve K5 + WVT sweep K9)",
+            "roofline": {"bound": "valu", "kernel": "k_iter (hsml / density solve K5%s)" % (" + fused f64 sweep K9" if args.sweep else ""),
                          "achieved": tflops, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / F64_VECTOR_PEAK_TFLOPS,
-                         "flop_model": "counted solver list visits/particle (stats pass of this run) x %g flop + %g flop "
-                                       "for the sweep (SURVEY.md 8d), all counted as f64" % (FLOP_PER_SOLVER_PAIR, FLOP_SWEEP_PER_PARTICLE),
+                         "flop_model": "counted solver list visits/particle (stats pass of this run) x %g flop (SURVEY.md 8d), "
+                                       "all counted as f64%s" % (FLOP_PER_SOLVER_PAIR, " + %g flop for the fused sweep" % FLOP_SWEEP_PER_PARTICLE if args.sweep else ""),
                          "solver_pair_evals_per_particle": st["pair_evals"], "queries_per_particle": st["queries"],
                          "candidates_per_particle": st["candidates"], "flop_per_particle": flop_per_particle,
                          "avg_launch_ms": 1e3 * dens_avg, "launches": dens_launch,
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_particle": BYTES_DENSITY_PER_PARTICLE,
                                  "whole_iteration_GBs": BYTES_ITER_PER_PARTICLE * n_total * args.steps / dt / 1e9 / world},
+                         "sweep_kernel": (None if args.sweep else
+                                          {"kernel": "k_wvt_exact4 (WVT sweep K9 in the reference's summation order: f32 accumulator, "
+                                                     "ascending index, one rounding per neighbour)",
+                                           "avg_launch_ms": 1e3 * sw_avg, "launches": sw_launch, "bound": "valu",
+                                           "achieved": sweep_tflops, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": sweep_tflops / F64_VECTOR_PEAK_TFLOPS,
+                                           "flop_model": "%g flop per particle (SURVEY.md 8d: ~350 pairs x ~40 flop)" % FLOP_SWEEP_PER_PARTICLE,
+                                           "hbm_GBs": BYTES_SWEEP_PER_PARTICLE * n_local / sw_avg / 1e9 if sw_avg > 0 else 0.0}),
                          "traffic": prof["traffic_bytes_per_launch"] if prof else None,
                          "profile": ({"source": "profiles/dominant_kernel.json (rocprofv3 --pmc passes, tools/profile_round2.sh); "
                                                 "file values from the profiling run, not measured by this run",
@@ -259,7 +298,9 @@ def main():
                             "stop_rule": "reference's own (wvt_relax.c:94-98); an absolute mean error < 1 % is not reached "
                                          "by the reference either (SURVEY.md 6)"} if relax_log else None),
             "cpu_baseline": cpu,
-            "phase_ms_per_step": {k: 1e3 * v[0] / args.steps for k, v in phases.items() if v[1]},
+            "phase_ms_per_step": mine["phase_ms_per_step"],
+            "phase_ms_note": "HIP events per phase in a second run of the same K steps; the wall-clock figure above was "
+                             "taken with the event records off",
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

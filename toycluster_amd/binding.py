@@ -182,6 +182,8 @@ class TcGpu:
 
     def set_option(self, name, value):
         self._ck(self._L.tcgpu_set_option(self._h, name.encode(), float(value)))
+        if name == "timing":
+            self._timing_on = bool(value)
 
     # ---- model / particles -------------------------------------------------------------
     def set_model(self, model):
