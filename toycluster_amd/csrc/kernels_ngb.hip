@@ -1864,16 +1864,23 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
                         nj = njend = 0u;
                         if (ri < nruns) { const uint2 r = pruns[(size_t)ri * 64]; ri++; nj = r.x; njend = r.y; }
                     }
-                    const float r2 = tc_ngb_r2(xi, yi, zi, pc.x, pc.y, pc.z, k.boxhalf_f, k.boxsize_f);
+                    /* the f32 predicate of src/tree.c:67-89; its folding cannot fire for an interior ball (wave-uniform) */
+                    const float r2 = ngb_r2_w(xi, yi, zi, pc.x, pc.y, pc.z, k.boxhalf_f, k.boxsize_f, wrap);
                     const bool hit = act && r2 < hq2;
-                    const uint32_t mh = quad_bits(tc_ballot(hit), lane);
-                    /* the reference's list ends at its NGBMAX-th entry (src/tree.c:91-92); the particle itself is on the
-                     * list but not in the sum (src/wvt_relax.c:141-142) */
-                    const bool keep = hit && nlist + (int)__popc(mh & below) < TC_NGBMAX && jc != (uint32_t)i;
+                    /* the particle itself is on the reference's list but not in the sum (src/wvt_relax.c:141-142); it is
+                     * among this step's candidates when i is in [j, j + 4) of the run (the same for the quad's four lanes) */
+                    bool keep = hit && jc != (uint32_t)i;
+                    const bool selfhere = !cdone && (uint32_t)i - j < 4u && (uint32_t)i < jend;
+                    if (tc_ballot(nlist + 4 >= TC_NGBMAX)) {
+                        /* some list of this wave is about to end at its NGBMAX-th entry (src/tree.c:91-92): a hit stays
+                         * only if its place on the list (hits before it in this step, the particle itself included) exists */
+                        const uint32_t mh = quad_bits(tc_ballot(hit), lane);
+                        keep = keep && nlist + (int)__popc(mh & below) < TC_NGBMAX;
+                    }
                     const uint32_t mk = quad_bits(tc_ballot(keep), lane);
                     if (keep) buf[cnt + (int)__popc(mk & below)] = pc;
                     cnt += (int)__popc(mk);
-                    nlist += (int)__popc(mh);
+                    nlist += (int)__popc(mk) + (selfhere ? 1 : 0);   /* length of the reference's list so far */
                     if (!cdone) {
                         j = j2; jend = jend2;
                         if (last) cdone = true;
