@@ -693,7 +693,7 @@ static int present(tcgpu_ctx *c)
         }
         if (rc) { tc_phase_end(c); return rc; }
     }
-    if ((rc = tc_launch_iota(c, c->idx, (size_t)c->n, 0))) return rc;
+    if ((rc = tc_launch_iota(c, c->idx, (size_t)c->n, 0))) { tc_phase_end(c); return rc; }
     int sort_levels = c->lmax + 5;
     if (sort_levels > 21) sort_levels = 21;
     if (tc_sort_pairs_u128(c->sort_tmp, c->sort_tmp_bytes, c->g_key, c->g_key_sorted, c->idx, c->idx_sorted, (size_t)c->n,
@@ -701,7 +701,7 @@ static int present(tcgpu_ctx *c)
         tc_phase_end(c);
         TC_FAIL(c, TCGPU_ERR_HIP, "radix sort failed");
     }
-    if ((rc = tc_launch_present_permute(c, c->idx_sorted))) return rc;
+    if ((rc = tc_launch_present_permute(c, c->idx_sorted))) { tc_phase_end(c); return rc; }
     TC_HIP(c, hipMemcpyAsync(c->g_key, c->g_key_sorted, (size_t)c->n * sizeof(tc_u128), hipMemcpyDeviceToDevice, c->stream));
     c->order_dirty = 0;
     c->keys_valid = 1;
@@ -767,6 +767,26 @@ static int ensure_pos_all(tcgpu_ctx *c)
  *   4. received positions land in g_pos4 at their global index; lsel = ascending union of own range and ghosts.
  * The local set that results is the one the flag pass over all positions selected (same bits, same test), so
  * everything downstream -- and the bit-identity with the single-rank run -- is unchanged. */
+/* Sharded passes: a failure that only ONE rank sees (an allocation sized by its own ghost counts, its table layout, a
+ * launch) must not let that rank return while the others post their sends and receives to it -- they would wait for
+ * ever.  The ranks therefore agree on the status before any point-to-point traffic: one scalar all-reduce (max) and a
+ * stream synchronisation, ~20 us per pass.  Every rank returns an error, or none does.   */
+static int agree_status(tcgpu_ctx *c, int rc_local, const char *what)
+{
+    if (!multi(c)) return rc_local;
+    double *buf = tc_pass_scalars(c) + 44;
+    const double mine = rc_local ? 1.0 : 0.0;
+    double any = 1.0;
+    if (hipMemcpyAsync(buf, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return rc_local ? rc_local : TCGPU_ERR_HIP;
+    if (allreduce_scalars(c, buf, 0, 1)) return rc_local ? rc_local : TCGPU_ERR_COMM;
+    if (hipMemcpyAsync(&any, buf, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess
+        || hipStreamSynchronize(c->stream) != hipSuccess)
+        return rc_local ? rc_local : TCGPU_ERR_HIP;
+    if (rc_local) return rc_local;
+    if (any != 0.0) TC_FAIL(c, TCGPU_ERR_COMM, "another rank failed in %s: pass abandoned on every rank", what);
+    return 0;
+}
+
 static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
 {
     const int R = c->nranks, me = c->rank;
@@ -786,47 +806,58 @@ static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
     if (rc) { tc_phase_end(c); return rc; }
     TC_HIP(c, hipMemcpyAsync(c->h_cnt_mat, c->ghost_cnt_mat, (size_t)R * R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     tc_phase_end(c);
-    if ((rc = tc_finish_local_layout(c))) return rc;                 /* synchronises: counts and table layout */
+    /* everything from here to the exchange can fail on one rank alone: the status is agreed before anybody sends */
     int soff[TC_GHOST_MAXR + 1], roff[TC_GHOST_MAXR + 1];
-    soff[0] = roff[0] = 0;
-    for (int q = 0; q < R; q++) {
-        soff[q + 1] = soff[q] + c->h_cnt_mat[(size_t)me * R + q];      /* row me: what I send to q (0 for q == me) */
-        roff[q + 1] = roff[q] + c->h_cnt_mat[(size_t)q * R + me];      /* column me: what q sends to me */
+    size_t nsend = 0, nrecv = 0;
+    auto prepare = [&]() -> int {
+        int r;
+        if ((r = tc_finish_local_layout(c))) return r;                /* synchronises: counts and table layout */
+        soff[0] = roff[0] = 0;
+        for (int q = 0; q < R; q++) {
+            soff[q + 1] = soff[q] + c->h_cnt_mat[(size_t)me * R + q];      /* row me: what I send to q (0 for q == me) */
+            roff[q + 1] = roff[q] + c->h_cnt_mat[(size_t)q * R + me];      /* column me: what q sends to me */
+        }
+        nsend = (size_t)soff[R]; nrecv = (size_t)roff[R];
+        {
+            /* Is this cheaper than sending every position to every rank?  Not when nearly everything is somebody's
+             * ghost (few particles per rank: thick shells) -- then the next passes all-gather instead and the question
+             * is asked again later.  Decided from the whole count matrix, so every rank decides the same. */
+            double ghosts = 0;
+            for (int q = 0; q < R * R; q++) ghosts += c->h_cnt_mat[q];
+            const double cost_ghost = ghosts * (sizeof(uint32_t) + sizeof(float4))
+                                      + (double)R * (R - 1) * (double)(c->pyr_chunk * sizeof(uint32_t));
+            const double cost_all = (double)R * (double)(c->n - c->shard_len) * sizeof(float4);
+            if (c->ghost_mode == 1 && c->margin_widen == 0 && cost_ghost > cost_all) c->ghost_pause = 7;   /* (a repeated pass
+                                                                                           * has a wider shell: not typical) */
+        }
+        if ((int64_t)nrecv + (hi - lo) > c->cap) TC_FAIL(c, TCGPU_ERR_NOMEM, "local set larger than the particle capacity");
+        if (nsend > c->send_cap) {
+            hipFree(c->send_idx); hipFree(c->send_pos);
+            c->send_idx = nullptr; c->send_pos = nullptr; c->send_cap = 0;
+            const size_t cap = nsend + nsend / 4 + 1024;
+            TC_HIP(c, hipMalloc(&c->send_idx, cap * sizeof(uint32_t)));
+            TC_HIP(c, hipMalloc(&c->send_pos, cap * sizeof(float4)));
+            c->send_cap = cap;
+        }
+        if (nrecv > c->ghost_cap) {
+            hipFree(c->ghost_idx); hipFree(c->ghost_pos);
+            c->ghost_idx = nullptr; c->ghost_pos = nullptr; c->ghost_cap = 0;
+            const size_t cap = nrecv + nrecv / 4 + 1024;
+            TC_HIP(c, hipMalloc(&c->ghost_idx, cap * sizeof(uint32_t)));
+            TC_HIP(c, hipMalloc(&c->ghost_pos, cap * sizeof(float4)));
+            c->ghost_cap = cap;
+        }
+        tc_phase_begin(c, PH_LOCAL);
+        r = tc_launch_ghost_fill(c);
+        tc_phase_end(c);
+        return r;
+    };
+    rc = prepare();
+    if (c->debug_fail_rank == me + 1 && !rc) {                        /* tests: a failure only this rank sees */
+        snprintf(c->err, sizeof(c->err), "injected failure on rank %d", me);
+        rc = TCGPU_ERR_NOMEM;
     }
-    const size_t nsend = (size_t)soff[R], nrecv = (size_t)roff[R];
-    {
-        /* Is this cheaper than sending every position to every rank?  Not when nearly everything is somebody's
-         * ghost (few particles per rank: thick shells) -- then the next passes all-gather instead and the question
-         * is asked again later.  Decided from the whole count matrix, so every rank decides the same. */
-        double ghosts = 0;
-        for (int q = 0; q < R * R; q++) ghosts += c->h_cnt_mat[q];
-        const double cost_ghost = ghosts * (sizeof(uint32_t) + sizeof(float4))
-                                  + (double)R * (R - 1) * (double)(c->pyr_chunk * sizeof(uint32_t));
-        const double cost_all = (double)R * (double)(c->n - c->shard_len) * sizeof(float4);
-        if (c->ghost_mode == 1 && c->margin_widen == 0 && cost_ghost > cost_all) c->ghost_pause = 7;   /* (a repeated pass
-                                                                                       * has a wider shell: not typical) */
-    }
-    if ((int64_t)nrecv + (hi - lo) > c->cap) TC_FAIL(c, TCGPU_ERR_NOMEM, "local set larger than the particle capacity");
-    if (nsend > c->send_cap) {
-        hipFree(c->send_idx); hipFree(c->send_pos);
-        c->send_idx = nullptr; c->send_pos = nullptr; c->send_cap = 0;
-        const size_t cap = nsend + nsend / 4 + 1024;
-        TC_HIP(c, hipMalloc(&c->send_idx, cap * sizeof(uint32_t)));
-        TC_HIP(c, hipMalloc(&c->send_pos, cap * sizeof(float4)));
-        c->send_cap = cap;
-    }
-    if (nrecv > c->ghost_cap) {
-        hipFree(c->ghost_idx); hipFree(c->ghost_pos);
-        c->ghost_idx = nullptr; c->ghost_pos = nullptr; c->ghost_cap = 0;
-        const size_t cap = nrecv + nrecv / 4 + 1024;
-        TC_HIP(c, hipMalloc(&c->ghost_idx, cap * sizeof(uint32_t)));
-        TC_HIP(c, hipMalloc(&c->ghost_pos, cap * sizeof(float4)));
-        c->ghost_cap = cap;
-    }
-    tc_phase_begin(c, PH_LOCAL);
-    rc = tc_launch_ghost_fill(c);
-    tc_phase_end(c);
-    if (rc) return rc;
+    if ((rc = agree_status(c, rc, "the ghost exchange's preparation"))) return rc;
     tc_phase_begin(c, PH_COMM);
     c->comm_bytes += (double)nrecv * (sizeof(uint32_t) + sizeof(float4));
     if (c->loop) {
@@ -904,6 +935,7 @@ static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
         tc_phase_begin(c, PH_LOCAL);
         rc = tc_launch_mark_interest(c);
         if (!rc) rc = tc_select_local(c, &nloc);                      /* synchronises: the launch sizes below need nloc */
+        tc_phase_end(c);
         if (rc) return rc;
         c->local_full = 0;
         c->nloc = nloc;
@@ -1404,6 +1436,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "no_records")) c->no_records = value != 0;    /* tests: the fall-back of k_prec / k_cprec */
     else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = c->lmax_rm0 = 0; }
     else if (!strcmp(name, "force_comm")) c->force_comm = value != 0;   /* tests: 1-rank RCCL communicator */
+    else if (!strcmp(name, "debug_fail_rank")) c->debug_fail_rank = (int)value;   /* tests: rank value - 1 fails before the ghost exchange */
     else if (!strcmp(name, "ghost_exchange")) c->ghost_mode = (int)value; /* 0: position all-gather every pass, 1: whichever is cheaper (default), 2: always ghosts */
     else if (!strcmp(name, "lmax")) {
         if (c->n > 0) TC_FAIL(c, TCGPU_ERR_ARG, "lmax must be set before tcgpu_upload_particles");

@@ -256,6 +256,7 @@ struct tcgpu_ctx {
     int rank, nranks;
     void *comm;                   /* ncclComm_t */
     int force_comm;
+    int debug_fail_rank;          /* option (tests): rank (value - 1) reports a failure of its own before the ghost exchange */
     struct tc_loop_comm *loop;    /* testing: in-process loopback communicator (threads + D2D copies) */
     int need_guess;               /* some hsml == 0: the first-pass guess is required */
     int64_t shard_len;
