@@ -702,7 +702,7 @@ def test_sharded_path_with_loopback_ranks(nranks, n, ghosts):
         assert min(o[2]["nloc"] for o in out) < 0.9 * n
 
 
-def test_failure_of_one_rank_before_the_ghost_exchange_is_everybody's(golden_case):
+def test_failure_of_one_rank_before_the_ghost_exchange_fails_all(golden_case):
     """A failure that only ONE rank sees while it prepares the ghost exchange (an allocation sized by its own counts,
     its table layout, a launch) used to make that rank return alone while the others posted sends and receives to it:
     a hang.  The ranks now agree on the status before any point-to-point traffic (agree_status, api.hip): with a failure

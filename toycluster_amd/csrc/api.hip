@@ -218,11 +218,12 @@ extern "C" int tcgpu_set_model(tcgpu_ctx *c, const tcgpu_params *par, const tcgp
     c->have_model = 1;
     c->w_valid = 0;
     /* unit of the exact sum of h^3 (k_model_hsml): the model density is nowhere above the sum of the central
-     * densities, so h^3 = 295 m / rho / (4 pi / 3) is nowhere below h3_min; 2^-30 of that keeps 30 bits under
+     * densities -- the cool-core component of a cuspy halo included (rho0 + rho0_cc at r = 0, setup.c:604-612) --
+     * so h^3 = 295 m / rho / (4 pi / 3) is nowhere below h3_min; 2^-30 of that keeps 30 bits under
      * the smallest term and 33 bits of head room above it in a 64-bit term. */
     double rho_up = 0;
     for (int i = 0; i < par->nhalos; i++)
-        if (halos[i].mass_gas != 0 && halos[i].rho0 > 0) rho_up += halos[i].rho0;
+        if (halos[i].mass_gas != 0 && halos[i].rho0 > 0) rho_up += halos[i].rho0 + (halos[i].rho0_cc > 0 ? halos[i].rho0_cc : 0.0);
     int e2 = 0;
     if (rho_up > 0) (void)frexp(TC_DESNNGB * par->mpart_gas / rho_up / TC_FOURPITHIRD, &e2);
     c->h3_unit = ldexp(1.0, e2 - 1 - 30);

@@ -446,22 +446,23 @@ __global__ __launch_bounds__(TB) void k_ghost_fill(const float4 *__restrict__ gp
                                                    float4 *__restrict__ send_pos)
 {
     __shared__ int s_w[TC_GHOST_MAXR][TB / 64];
+    __shared__ uint64_t s_b[TC_GHOST_MAXR][TB / 64];           /* the wave's lane mask per destination */
     const int g = lo + blockIdx.x * TB + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t m = g < hi ? mask[g - lo] : 0u;
-    uint32_t any = 0;                                           /* destinations present in this wave */
+    /* every wave intrinsic sits in this loop, which all 64 lanes run together; below, lanes leave and skip at will and
+     * only read the masks back (a ballot behind a divergent return relies on reconvergence the language
+     * does not promise) */
     for (int q = 0; q < R; q++) {
         const uint64_t b = __ballot((m >> q) & 1u);
-        if (lane == 0) s_w[q][wave] = (int)__popcll(b);
-        if (b) any |= 1u << q;
+        if (lane == 0) { s_w[q][wave] = (int)__popcll(b); s_b[q][wave] = b; }
     }
     __syncthreads();
     if (!m) return;
     const float4 p = gpos4[g];
     for (int q = 0; q < R; q++) {
-        if (!((any >> q) & 1u)) continue;
-        const uint64_t b = __ballot((m >> q) & 1u);             /* lanes with m == 0 have left: they are not in b anyway */
         if (!((m >> q) & 1u)) continue;
+        const uint64_t b = s_b[q][wave];
         const size_t e = (size_t)q * nblk + blockIdx.x;
         int off = incl[e] - blk_cnt[e];
         for (int w = 0; w < wave; w++) off += s_w[q][w];
@@ -1294,7 +1295,7 @@ int tc_launch_error(tcgpu_ctx *c)
 /* ------------------------------------------------------------------ K7/K8 model hsml */
 
 /* src/wvt_relax.c:108-118 over the own range.  h^3 (f32) enters the sum as the integer trunc(h^3 / unit), `unit` a
- * power of two 2^30 below the smallest h^3 the model allows (tc_h3_unit): exact for density contrasts up to 2^33. */
+ * power of two 2^30 below the smallest h^3 the model allows (tcgpu_set_model: h3_unit): exact for density contrasts up to 2^33. */
 __global__ __launch_bounds__(TB) void k_model_hsml(const float4 *__restrict__ pos4, int lo, int hi, double boxhalf,
                                                    double mpart, double inv_unit, const tc_halo_dev *__restrict__ halo, int nhalos,
                                                    float *__restrict__ rhom, float *__restrict__ hw,
