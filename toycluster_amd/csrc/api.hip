@@ -1432,7 +1432,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
     else if (!strcmp(name, "sweep")) c->sweep_mode = value != 0;         /* 0: the reference's order and roundings (default); 1: f64 sums, rounded once */
     else if (!strcmp(name, "xsweep_shift")) c->xsweep_shift = (int)value;
-    else if (!strcmp(name, "xsweep_kernel")) c->xsweep_kernel = value != 0;
+    else if (!strcmp(name, "xsweep_kernel")) c->xsweep_kernel = (int)value;
     else if (!strcmp(name, "curl_literal")) c->curl_literal = value != 0;
     else if (!strcmp(name, "no_records")) c->no_records = value != 0;    /* tests: the fall-back of k_prec / k_cprec */
     else if (!strcmp(name, "rows")) { c->rows = value != 0; c->mirror_valid = 0; if (!c->rows) c->lmax_rm = c->lmax_rm0 = 0; }

@@ -2003,8 +2003,10 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
     tc_phase_begin(c, PH_WVT);
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     /* option "xsweep_kernel" = 1 (tests): the one-lane-per-particle kernel on the (x, y, z) cell table -- an independent
-     * second implementation of the same sums */
-    if (c->xsweep_kernel) k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
+     * second implementation of the same sums.  (A third layout -- one lane per particle with candidates served from LDS
+     * tiles of the index space -- was tried in round 3 and dropped: the Peano runs of a ball are short and scattered, a
+     * group of 64 particles touches hundreds of 128-particle tiles: 26 ms.) */
+    if (c->xsweep_kernel == 1) k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
     else k_wvt_exact4<<<g4, TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
