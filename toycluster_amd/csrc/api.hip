@@ -169,6 +169,7 @@ static void free_particles(tcgpu_ctx *c)
     TC_FREE(c->key); TC_FREE(c->key_sorted); TC_FREE(c->idx); TC_FREE(c->idx_sorted); TC_FREE(c->sort_tmp);
     TC_FREE(c->cells); TC_FREE(c->guess); TC_FREE(c->hwvt); TC_FREE(c->delta); TC_FREE(c->stats); TC_FREE(c->ngb_buf);
     TC_FREE(c->ustep); TC_FREE(c->rhom_next); TC_FREE(c->prec); TC_FREE(c->xruns); c->xruns_bytes = 0;
+    TC_FREE(c->xr); TC_FREE(c->xrn); TC_FREE(c->xlist); TC_FREE(c->xlcnt); TC_FREE(c->xun); c->xr_cap = 0; c->xlist_valid = 0;
     TC_FREE(c->cum); TC_FREE(c->scan_tmp); TC_FREE(c->mirror); TC_FREE(c->mirror_idx);
     TC_FREE(c->pf); TC_FREE(c->pf_tmp); c->pf_alloc = 0; c->pf_valid = 0;
     c->cum_alloc = c->mirror_alloc = 0; c->mirror_valid = 0;
@@ -268,7 +269,12 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         TC_HIP(c, hipMalloc(&c->lsel, cap * sizeof(uint32_t)));
         TC_HIP(c, hipMalloc(&c->lg, cap * sizeof(uint32_t)));
         TC_HIP(c, hipMalloc(&c->own_list, cap * sizeof(uint32_t)));
-        TC_HIP(c, hipMalloc(&c->pos4, cap * sizeof(float4)));
+        TC_HIP(c, hipMalloc(&c->pos4, (cap + 1) * sizeof(float4)));
+        {   /* one extra slot infinitely far away (index cap): padding lanes of the ordered gather load it */
+            const float inf = HUGE_VALF;
+            const float4 far = make_float4(inf, inf, inf, 0.0f);
+            TC_HIP(c, hipMemcpy(c->pos4 + cap, &far, sizeof(far), hipMemcpyHostToDevice));
+        }
         TC_HIP(c, hipMalloc(&c->hsml, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->hsml0, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->rho, cap * sizeof(float)));
@@ -912,7 +918,7 @@ static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
 static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
 {
     int rc;
-    c->index_valid = 0; c->mirror_valid = 0; c->ustep_valid = 0; c->pf_valid = 0;
+    c->index_valid = 0; c->mirror_valid = 0; c->ustep_valid = 0; c->pf_valid = 0; c->xlist_valid = 0;
     if (!multi(c)) full = 1;
     if (full) {
         if ((rc = ensure_pos_all(c))) return rc;
@@ -1105,12 +1111,15 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
     if (c->fuse) {
         /* one gather per particle serves the density solve and (with_wvt) the WVT sweep that
          * follows on the same positions */
-        if ((rc = tc_launch_mirror(c))) return rc;
         /* the sweep rides along only in round 2's mode (f64 sums, one rounding); the default sweep reproduces the
          * reference's order and roundings in a kernel of its own (k_wvt_exact), after the step is known */
-        const int ride = with_wvt && c->sweep_mode == 1;
+        const int ride = !with_wvt ? 0 : c->sweep_mode == 1 ? 1 : (c->sweep_mode == 0 && !c->xsweep_kernel) ? 2 : 0;
+        if (ride == 2) {                                                            /* the ordered runs come from pf; */
+            if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;              /* nobody needs the mirror */
+        } else if ((rc = tc_launch_mirror(c))) return rc;
         if ((rc = tc_launch_iter(c, ride))) return rc;
-        c->ustep_valid = ride;
+        c->ustep_valid = ride == 1;
+        c->xlist_valid = ride == 2;
     } else if ((rc = tc_launch_density(c))) return rc;
     return 0;
 }
@@ -1222,7 +1231,7 @@ static int wvt_step_nocheck(tcgpu_ctx *c, double step, int move)
             c->local_w_valid = 1;
         }
         if ((rc = tc_launch_commit_rhom(c))) return rc;
-        if (c->sweep_mode == 0) {
+        if (c->sweep_mode != 1) {
             /* the exact sweep walks the cells in curve order: their index ranges come from the sorted keys of the
              * local set (key_sorted stays valid as long as the local order does) */
             if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;
@@ -1418,6 +1427,33 @@ extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *
     return TCGPU_OK;
 }
 
+/* diagnostics (tools/): how the ordered gather went in the last WVT == 2 pass -- out[0] own particles, [1] with a run list,
+ * [2] with a neighbour list, [3] mean runs, [4] mean listed neighbours, [5] max runs, [6] max listed */
+extern "C" int tcgpu_debug_xlist_stats(tcgpu_ctx *c, double *out)
+{
+    if (!c || !out || !c->xrn || !c->xlcnt) return TCGPU_ERR_ARG;
+    TC_HIP(c, hipSetDevice(c->device));
+    TC_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->nloc;
+    uint32_t *a = (uint32_t *)malloc(n * 4), *b = (uint32_t *)malloc(n * 4), *own = (uint32_t *)malloc(n * 4);
+    hipError_t e = hipMemcpy(a, c->xrn, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(b, c->xlcnt, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && c->nranks > 1) e = hipMemcpy(own, c->own_list, (size_t)c->nown * 4, hipMemcpyDeviceToHost);
+    for (int q = 0; q < 7; q++) out[q] = 0;
+    if (e == hipSuccess)
+        for (int64_t t = 0; t < c->nown; t++) {
+            const size_t i = c->nranks > 1 ? own[t] : (size_t)t;
+            out[0] += 1;
+            if (a[i] != TC_XNONE) { out[1] += 1; out[3] += a[i]; if (a[i] > out[5]) out[5] = a[i]; }
+            if (b[i] != TC_XNONE) { out[2] += 1; out[4] += b[i]; if (b[i] > out[6]) out[6] = b[i]; }
+        }
+    if (out[1] > 0) out[3] /= out[1];
+    if (out[2] > 0) out[4] /= out[2];
+    free(a); free(b); free(own);
+    TC_HIP(c, e);
+    return TCGPU_OK;
+}
+
 /* ------------------------------------------------------------------ options / timing */
 
 extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
@@ -1430,7 +1466,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
     else if (!strcmp(name, "blocks_per_cu")) c->blocks_per_cu = (int)value;   /* profiling: cap the persistent grid */
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
-    else if (!strcmp(name, "sweep")) c->sweep_mode = value != 0;         /* 0: the reference's order and roundings (default); 1: f64 sums, rounded once */
+    else if (!strcmp(name, "sweep")) c->sweep_mode = (int)value;         /* 0: the reference's order and roundings, lists from k_iter (default); 2: the same, stand-alone; 1: f64 sums, rounded once */
     else if (!strcmp(name, "xsweep_shift")) c->xsweep_shift = (int)value;
     else if (!strcmp(name, "xsweep_kernel")) c->xsweep_kernel = (int)value;
     else if (!strcmp(name, "curl_literal")) c->curl_literal = value != 0;

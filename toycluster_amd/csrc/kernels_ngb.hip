@@ -676,6 +676,75 @@ __device__ __forceinline__ uint32_t stream_rows_q(const tc_dev_const &k, const t
     return ncand;
 }
 
+/* The same streaming with the rows replaced by a particle's ordered index runs (k_xruns: the cells of the ball in CURVE
+ * order, each a contiguous run of the Peano-sorted positions themselves): the flat candidate number then ascends with
+ * the particle index, so everything downstream -- hit lists, staged sweep neighbours -- comes out in ascending index,
+ * the order the reference's lists have (src/tree.c:25-111).  No mirror, no per-row geometry in this kernel. */
+template <class Body>
+__device__ __forceinline__ uint32_t stream_runs(const tc_dev_const &k, const uint2 *__restrict__ pruns, int nruns,
+                                               uint32_t *heads, Body &&body TC_PROF_PARAM)
+{
+    const int lane = lane_id();
+    TC_STAGE_SWITCH(ST_PROLOGUE, ST_PRODUCER);
+    const tc_gpos posv = vgpr_pos(k.pos4);
+    const uint32_t padslot = vgpr_u32(k.pos_pad);
+    uint32_t ncand = 0;
+    for (int rbase = 0; rbase < nruns; rbase += 64) {
+        uint32_t ra = 0, rb = 0;
+        if (rbase + lane < nruns) { const uint2 r = pruns[rbase + lane]; ra = r.x; rb = r.y; }
+        const uint32_t cnt = rb - ra;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t excl = incl - cnt;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t bprev = (uint32_t)__shfl_up((int)rb, 1);
+        if (lane == 0) bprev = 0;
+        const uint32_t jump = ra - bprev;
+        ncand += total;
+        uint32_t carry = 0;
+        auto slots = [&](uint32_t base, uint32_t (&j)[4]) {
+            reinterpret_cast<uint4 *>(heads)[lane] = make_uint4(0, 0, 0, 0);
+            wave_lds_fence();
+            if (excl >= base && excl < base + 256 && excl < total) atomicAdd(&heads[excl - base], jump);
+            wave_lds_fence();
+            uint32_t hsum[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) hsum[u] = heads[64 * u + lane];
+            wave_incl_scan4(hsum[0], hsum[1], hsum[2], hsum[3]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t sc = hsum[u] + carry;
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)hsum[u], 63);
+                const uint32_t m = base + 64 * u + lane;
+                j[u] = m < total ? m + sc : padslot;
+            }
+            wave_lds_fence();
+        };
+        uint32_t j[4], jn[4];
+        TC_STAGE_SWITCH(ST_PRODUCER, ST_WINDOW);
+        if (total > 0) slots(0, j);
+        TC_STAGE_SWITCH(ST_WINDOW, ST_PRODUCER);
+        for (uint32_t base = 0; base < total; base += 256) {
+            TC_STAGE_SWITCH(ST_PRODUCER, ST_WINDOW);
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = ld3(posv, j[u]);
+            if (base + 256 < total) slots(base + 256, jn);
+            TC_STAGE_SWITCH(ST_WINDOW, ST_TEST);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (base + 64 * u < total) {
+                    if (body(j[u], p[u], true)) return ncand;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) j[u] = jn[u];
+            TC_STAGE_SWITCH(ST_TEST, ST_PRODUCER);
+        }
+    }
+    TC_STAGE_SWITCH(ST_PRODUCER, ST_EPILOGUE);
+    return ncand;
+}
+
 /* Persistent-grid work assignment: a dynamic queue, XCD-aware.
  *
  * The instruction arbiter favours the oldest wave of a SIMD, so with a static assignment the four waves of a
@@ -1089,6 +1158,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->lmax_rm = rm ? c->lmax_rm : 0;
     k->lmin_rm = rm ? c->lmin_rm : 1;
     k->mirror_pad = (uint32_t)c->mirror_alloc;
+    k->pos_pad = (uint32_t)c->cap;
     k->n = (int)c->nloc;
     k->lo = 0;
     k->hi = (int)c->nown;
@@ -1342,6 +1412,11 @@ struct tc_xwvt_args {
     int xshift;         /* added to the query level (tuning: coarser leaves = fewer cells to walk, more candidates to test) */
     int orphans_only;   /* k_wvt_exact: run only when the local set has orphans (k_wvt_exact4 did the launch otherwise) */
     int dbg;            /* profiling only (results invalid): 1 = stop after A1, 2 = no B */
+    const uint32_t *xlist, *xlcnt;   /* k_iter's neighbour lists (WVT == 2): k_wvt_chain4 evaluates them, k_wvt_exact4 then only
+                                      * takes the particles without a list ... */
+    const uint32_t *wl;              /* ... which k_iter wrote down (local slots), *wl_cnt of them: the work items, 16 per wave so
+                                      * that a handful of particles does not cost the latency of a 64-particle group */
+    const int *wl_cnt;
     const uint32_t *pf; /* cell starts in curve order (tc_launch_pfirst), levels pf_lmin..lmax, entries biased per level */
     int pf_lmin;
 };
@@ -1355,15 +1430,15 @@ __device__ __forceinline__ float cell_gap(float x, int c, float s, float box)
     return fminf(g, alt);
 }
 
-/* groups of 64 consecutive work items, XCD-aware like work_queue(): f(first, stop) */
+/* groups of `chunk` (a power of two <= 64) consecutive work items, XCD-aware like work_queue(): f(first, stop) */
 template <class F>
-__device__ __forceinline__ void work_queue64(const tc_dev_const &k, F &&f)
+__device__ __forceinline__ void work_queue64(const tc_dev_const &k, F &&f, int chunk = 64)
 {
     const int lo = k.lo, hi = k.hi;
     const bool grouped = gridDim.x >= 16 && (gridDim.x & 7) == 0;
     const int ngroups = grouped ? 8 : 1;
     int glen = grouped ? ((hi - lo + 7) >> 3) : (hi - lo);
-    glen = (glen + 63) & ~63;
+    glen = (glen + chunk - 1) & ~(chunk - 1);
     const int g0 = grouped ? (int)(blockIdx.x & 7) : 0;
     for (int gg = 0; gg < ngroups; gg++) {
         const int grp = (g0 + gg) & (ngroups - 1);
@@ -1374,11 +1449,11 @@ __device__ __forceinline__ void work_queue64(const tc_dev_const &k, F &&f)
         for (;;) {
             uint32_t got = 0;
             if ((threadIdx.x & 63) == 0)
-                got = atomicAdd(reinterpret_cast<unsigned int *>(&k.work_ctr[16 * grp]), 64u);
+                got = atomicAdd(reinterpret_cast<unsigned int *>(&k.work_ctr[16 * grp]), (unsigned int)chunk);
             got = U(got);
             if (got >= (uint32_t)(gend - gstart)) break;
             const int base = gstart + (int)got;
-            f(base, base + 64 < gend ? base + 64 : gend);
+            f(base, base + chunk < gend ? base + chunk : gend);
         }
     }
 }
@@ -1773,7 +1848,10 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
         lds_perm[t] = (unsigned char)cm;
     }
     __syncthreads();
-    const tc_dev_const &k = a.k;
+    tc_dev_const kw = a.k;
+    const int group = a.wl ? 16 : 64;                          /* work items per wave and turn */
+    if (a.wl) { kw.lo = 0; kw.hi = *a.wl_cnt; kw.own = a.wl; }
+    const tc_dev_const &k = kw;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     uint32_t *stk = reinterpret_cast<uint32_t *>(lds_hits4 + (size_t)wave * 16 * TC_X4CAP);
     const int q = lane >> 2, lq = lane & 3;
@@ -1789,9 +1867,9 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
         /* ---- A1, one lane per particle */
         {
             const int t = base + lane;
-            const bool valid = t < stop;
-            const int tt = valid ? t : base;
+            const int tt = t < stop ? t : base;
             const int i = k.own ? (int)k.own[tt] : tt;
+            const bool valid = t < stop;
             const float4 pi = k.pos4[i];
             const float hq = (float)((double)pi.w * k.boxsize);
             int lmin = k.lmin_tab, lmaxp = k.lmax;
@@ -1816,9 +1894,9 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
             if (base + 16 * pass >= stop) break;
             const int pl = 16 * pass + q;
             const int t = base + pl;
-            const bool valid = t < stop;
-            const int tt = valid ? t : base;
+            const int tt = t < stop ? t : base;
             const int i = k.own ? (int)k.own[tt] : tt;
+            const bool valid = t < stop;
             const float4 pi = k.pos4[i];
             const float xi = pi.x, yi = pi.y, zi = pi.z;
             const float hq = (float)((double)pi.w * k.boxsize);             /* src/wvt_relax.c:135 */
@@ -1958,6 +2036,100 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
             }
             if (valid && lq < 3) a.delta[3 * (size_t)a.lg[i] + lq] = dacc;
         }
+    }, group);
+}
+
+/* The sweep on k_iter's neighbour lists (WVT == 2): the lists are in ascending index already, so what is left of the
+ * exact sweep is phase B alone -- four lanes per particle read four list entries and their positions per step, evaluate
+ * src/wvt_relax.c:141-169 statement for statement and add the terms to the f32 accumulators in order (as k_wvt_exact4). */
+__global__ __launch_bounds__(TBN) void k_wvt_chain4(tc_xwvt_args a)
+{
+    __shared__ double lds_terms[WPB * 64 * 3];
+    const tc_dev_const &k = a.k;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int q = lane >> 2, lq = lane & 3;
+    double *tq = lds_terms + ((size_t)wave * 16 + q) * 12;
+    const int lc = lq < 3 ? lq : 0;
+    const double boxinv = k.boxinv;
+    work_queue64(k, [&](int base, int stop) {
+        for (int pass = 0; pass < 4; pass++) {
+            if (base + 16 * pass >= stop) break;
+            const int t = base + 16 * pass + q;
+            const int tt = t < stop ? t : base;
+            const int i = k.own ? (int)k.own[tt] : tt;
+            const uint32_t nl = a.xlcnt[i];
+            const bool valid = t < stop && nl != TC_XNONE;
+            const int cnt = valid ? (int)nl : 0;
+            const float4 pi = k.pos4[i];
+            const float xi = pi.x, yi = pi.y, zi = pi.z;
+            const float hq = (float)((double)pi.w * k.boxsize);
+            const double ext = (double)hq * (1.0 + 1e-5) + k.boxsize * 1e-5;
+            const bool wrap = tc_ballot(valid && !((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
+                                                   && (double)yi <= k.boxsize - ext && (double)zi >= ext && (double)zi <= k.boxsize - ext)) != 0;
+            const double step_hi = a.step * (double)pi.w;                   /* step * hsml[ipart], src/wvt_relax.c:167 */
+            const uint32_t *lst = a.xlist + (size_t)i * TC_XLCAP;
+            float dacc = 0;
+            /* the list entry and the position of the next step are requested before this step's are looked at */
+            uint32_t jn = lq < cnt ? lst[lq] : (uint32_t)i;
+            float4 pn = k.pos4[jn];
+            for (int s = 0; tc_ballot(s < cnt); s += 4) {
+                const bool ok = s + lq < cnt;
+                const float4 pj = pn;
+                const uint32_t j2 = s + 4 + lq < cnt ? lst[s + 4 + lq] : (uint32_t)i;
+                pn = k.pos4[j2];
+                float dx = (float)((double)(xi - pj.x) * boxinv);
+                float dy = (float)((double)(yi - pj.y) * boxinv);
+                float dz = (float)((double)(zi - pj.z) * boxinv);
+                if (wrap) {                                             /* wave-uniform */
+                    dx = dx > 0.5f ? dx - 1.0f : dx;                    /* src/wvt_relax.c:148-154 (0.5 is exact in f32) */
+                    dy = dy > 0.5f ? dy - 1.0f : dy;
+                    dz = dz > 0.5f ? dz - 1.0f : dz;
+                    dx = dx < -0.5f ? dx + 1.0f : dx;
+                    dy = dy < -0.5f ? dy + 1.0f : dy;
+                    dz = dz < -0.5f ? dz + 1.0f : dz;
+                }
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                const float h = (float)(0.5 * (double)(pi.w + pj.w));
+                const bool in = ok && !(r2 > h * h);
+                double e0 = 0, e1 = 0, e2 = 0;
+                {
+                    const float r = tc_sqrt_f32_lean_pos(r2);                    /* == (float)sqrt((double)r2) */
+                    const double u = (double)tc_div_f32_lean(r, h);              /* src/wvt_relax.c:277: f32 quotient */
+                    const double tt8 = 1 - u;
+                    const float wk = (float)(TC_WC6_NORM * tt8 * tt8 * tt8 * tt8 * tt8 * tt8 * tt8 * tt8
+                                             * (1 + 8 * u + 25 * u * u + 32 * u * u * u));
+                    const double b = step_hi * (double)wk;
+                    const double rd = (double)r;
+                    double y = __builtin_amdgcn_rcp(rd);
+                    double ee = __builtin_fma(-rd, y, 1.0);
+                    y = __builtin_fma(y, ee, y);
+                    ee = __builtin_fma(-rd, y, 1.0);
+                    y = __builtin_fma(y, ee, y);
+                    const double n0 = b * (double)dx, n1 = b * (double)dy, n2 = b * (double)dz;
+                    const double q0 = n0 * y, q1 = n1 * y, q2 = n2 * y;
+                    if (in) {
+                        e0 = __builtin_fma(__builtin_fma(-rd, q0, n0), y, q0);
+                        e1 = __builtin_fma(__builtin_fma(-rd, q1, n1), y, q1);
+                        e2 = __builtin_fma(__builtin_fma(-rd, q2, n2), y, q2);
+                    }
+                }
+                if (tc_ballot(in && r2 < 1e-24f)) {                     /* coincident particles: the IEEE sequences (0 / 0 and all) */
+                    if (in && r2 < 1e-24f) {
+                        const float r = sqrtf(r2);
+                        const float wk = (float)tc_wvt_wc6(r, h);
+                        e0 = step_hi * (double)wk * (double)dx / (double)r;
+                        e1 = step_hi * (double)wk * (double)dy / (double)r;
+                        e2 = step_hi * (double)wk * (double)dz / (double)r;
+                    }
+                }
+                tq[3 * lq] = e0; tq[3 * lq + 1] = e1; tq[3 * lq + 2] = e2;
+                wave_lds_fence();
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) dacc = (float)((double)dacc + tq[3 * kk + lc]);   /* src/wvt_relax.c:167-169 */
+                wave_lds_fence();
+            }
+            if (valid && lq < 3) a.delta[3 * (size_t)a.lg[i] + lq] = dacc;
+        }
     });
 }
 
@@ -1986,6 +2158,11 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
     a.flags = c->flags;
     a.xshift = c->xsweep_shift;
     a.dbg = c->ablate;
+    const bool lists = c->xlist_valid && c->sweep_mode == 0 && !c->xsweep_kernel;
+    a.xlist = lists ? c->xlist : nullptr;
+    a.xlcnt = lists ? c->xlcnt : nullptr;
+    a.wl = lists ? c->xun : nullptr;
+    a.wl_cnt = lists ? (const int *)(c->xun + c->xr_cap) : nullptr;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     const int g4 = xgrid(c, nloc, k_wvt_exact4), g1 = xgrid(c, nloc, k_wvt_exact);
@@ -2001,13 +2178,17 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
     a.pf_lmin = c->pf_lmin;
     a.orphans_only = 0;
     tc_phase_begin(c, PH_WVT);
+    if (lists) {                                  /* k_iter listed the neighbours in index order: evaluate the lists ... */
+        TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
+        k_wvt_chain4<<<xgrid(c, nloc, k_wvt_chain4), TBN, 0, c->stream>>>(a);
+    }                                             /* ... and k_wvt_exact4 below takes the particles that have none */
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     /* option "xsweep_kernel" = 1 (tests): the one-lane-per-particle kernel on the (x, y, z) cell table -- an independent
      * second implementation of the same sums.  (A third layout -- one lane per particle with candidates served from LDS
      * tiles of the index space -- was tried in round 3 and dropped: the Peano runs of a ball are short and scattered, a
      * group of 64 particles touches hundreds of 128-particle tiles: 26 ms.) */
     if (c->xsweep_kernel == 1) k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
-    else k_wvt_exact4<<<g4, TBN, 0, c->stream>>>(a);
+    else k_wvt_exact4<<<lists && g4 > 512 ? 512 : g4, TBN, 0, c->stream>>>(a);      /* lists: only the few particles without one */
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
@@ -2045,10 +2226,23 @@ struct tc_prec {
 #define TC_PREC_FULL0 8u              /* FULL0 << d: dimension d covers the whole ring (nd = 2^qL) */
 #define TC_PREC_VALID 64u             /* the record describes the query (else: work it out in the kernel) */
 
+/* compile-time flavours of the gather of k_iter: std::true_type = mirror slots of an interior ball (no folding, positions and
+ * "self" through the mirror), std::false_type = particle indices with the folding decided at run time, tc_tag_ord = particle
+ * indices of an interior ball (no folding), positions through the parked pointer */
+struct tc_tag_ord { static constexpr bool value = true; };
+
 struct tc_iter_args {
     tc_density_args d;
-    double *ustep;             /* 3n, unit-step displacement sums; NULL => density only */
+    double *ustep;             /* 3n, unit-step displacement sums (WVT == 1) */
     const tc_prec *prec;       /* one record per local slot of an own particle */
+    /* WVT == 2: the candidates come in ascending index from per-particle run lists (k_xruns), and the sweep's
+     * neighbours leave the kernel as index lists in that order for k_wvt_chain4 */
+    const uint2 *xr;           /* [i * TC_XRCAP + s] */
+    const uint32_t *xrn;       /* runs of particle i, TC_XNONE: none */
+    uint32_t *xlist;           /* [i * TC_XLCAP + s] */
+    uint32_t *xlcnt;           /* neighbours listed, TC_XNONE: not listed (k_wvt_exact4 takes the particle) */
+    uint32_t *xun;             /* ... and the particles not listed, *xun_cnt of them */
+    int *xun_cnt;
 };
 
 __global__ __launch_bounds__(256) void k_prec(tc_dev_const k0, const float *__restrict__ hsml_in, int do_wvt,
@@ -2116,7 +2310,7 @@ extern "C" int tcgpu_debug_wave_spans(uint64_t *out, int nwaves)
 
 /* STATS: keep the per-particle work counters (queries, solver iterations, pair evaluations, candidates) that
  * tcgpu_last_density_stats reports; without them the counters are dead code and cost no scalar registers */
-template <bool STATS, bool WVT>
+template <bool STATS, int WVT>      /* WVT: 0 density only, 1 + round 2's f64 sweep sums, 2 + the sweep's neighbours listed in index order */
 __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned char *mine, double *spill TC_PROF_PARAM)
 {
     TC_STAGE_SWITCH(ST_QUEUE, ST_PROLOGUE);
@@ -2131,7 +2325,11 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     const tc_dev_const &k = da.k;
     const float4 pi = make_float4(U(pv.x), U(pv.y), U(pv.z), U(pv.w));
     const float xi = pi.x, yi = pi.y, zi = pi.z;
-    constexpr bool do_wvt = WVT;                       /* a.ustep != nullptr */
+    constexpr bool do_wvt = WVT != 0;
+    constexpr bool ord = WVT == 2;
+    /* WVT == 2: this particle's ordered runs, if it has them */
+    const uint32_t nxr = ord ? U(a.xrn[i]) : TC_XNONE;
+    int cwout = 0;                                     /* sweep neighbours written to the list */
 
     double *lds_lists = reinterpret_cast<double *>(mine);
     uint32_t *idx = reinterpret_cast<uint32_t *>(lds_lists + TC_ICAP + TC_OCAP);
@@ -2184,7 +2382,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         /* the gather below is compiled twice (tag F): on the row-run path nothing wraps, positions come
          * from the mirror and "self" is the slot whose Peano index is i -- all compile-time there */
 
-        const tc_gpos vmirror = vgpr_pos(k.mirror);
+        const tc_gpos vmirror = vgpr_pos(ord ? k.pos4 : k.mirror);   /* WVT == 2 never touches the mirror */
         tc_list2 L;
         L.in.lds = lds_lists;            L.in.spill = spill;               L.in.cap = TC_ICAP;
         L.out.lds = lds_lists + TC_ICAP; L.out.spill = spill + TC_NGBMAX;  L.out.cap = TC_OCAP;
@@ -2203,12 +2401,19 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         /* 64 staged sweep hits -> pair terms */
         auto convert_w = [&](auto ftag, int nvalid) {
             constexpr bool F = decltype(ftag)::value;
+            constexpr bool MIR = std::is_same<std::decay_t<decltype(ftag)>, std::true_type>::value;
             const bool wr = F ? false : wrap;
             TC_STAGE_SWITCH(ST_CONVERT_D, ST_CONVERT_W);
             wave_lds_fence();
             int sl = (whead + lane) & (TC_STAGE - 1);
-            const float4 p = F ? ld4(vmirror, lane < nvalid ? wj[sl] : 0u) : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
+            if (ord) {
+                /* the neighbours reach this point in ascending index: 64 more entries of the particle's list */
+                if (lane < nvalid && cwout + lane < TC_XLCAP) a.xlist[(size_t)i * TC_XLCAP + cwout + lane] = wj[sl];
+                cwout = U(cwout + nvalid);
+            } else {
+            const float4 p = MIR ? ld4(vmirror, lane < nvalid ? wj[sl] : 0u) : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];
             if (lane < nvalid && TC_ABLATE(k) != 3) wvt_pair(pi, p, boxinv, step_hi, u0, u1, u2, wr);
+            }
             whead = U((whead + 64) & (TC_STAGE - 1));
             wave_lds_fence();
             TC_STAGE_SWITCH(ST_CONVERT_W, ST_CONVERT_D);
@@ -2221,6 +2426,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
          * plain code, which is exact whenever it runs). */
         auto convert_d = [&](auto ftag) -> bool {
             constexpr bool F = decltype(ftag)::value;
+            constexpr bool MIR = std::is_same<std::decay_t<decltype(ftag)>, std::true_type>::value;
+            constexpr bool PARK = MIR || std::is_same<std::decay_t<decltype(ftag)>, tc_tag_ord>::value;
             const bool wr = F ? false : wrap;
             TC_STAGE_SWITCH(ST_TEST, ST_CONVERT_D);
             wave_lds_fence();
@@ -2229,7 +2436,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             const float r2 = dr2[sl];
             /* the gather of the 64 positions is issued first; the sweep's part of the work -- which only needs the
              * staged index and r2, and every other time runs a whole batch of pair terms -- goes on underneath it */
-            const float4 pj = F ? ld3(vmirror, jj) : k.pos4[jj];        /* 12 bytes: no register of the gather is free for reuse */
+            const float4 pj = PARK ? ld3(vmirror, jj) : k.pos4[jj];     /* 12 bytes: no register of the gather is free for reuse */
             dhead = U((dhead + 64) & (TC_STAGE - 1));
             if (do_wvt) {
                 const bool hwv = r2 < hwsq;
@@ -2239,7 +2446,7 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                  * neighbour: found once per particle, so the test sits behind a wave-uniform branch */
                 bool use = hwv;
                 if (tc_ballot(r2 == 0.0f)) {
-                    const bool self = r2 == 0.0f && (F ? k.mirror_idx[jj] == (uint32_t)i : jj == (uint32_t)i);
+                    const bool self = r2 == 0.0f && (MIR ? k.mirror_idx[jj] == (uint32_t)i : jj == (uint32_t)i);
                     use = hwv && !self;
                     mw = tc_ballot(use);
                 }
@@ -2297,7 +2504,22 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             return false;
         };
         bool overflow;
-        if (fast) {
+        if (ord && nxr != TC_XNONE) {
+            /* candidates in ascending index from the particle's run list; an interior ball needs no folding */
+            auto run_it = [&](auto F) {
+                d.ncand += stream_runs(k, a.xr + (size_t)i * TC_XRCAP, (int)nxr, idx,
+                                       [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); } TC_PROF_PASS);
+                overflow = stopped || cs + co + dcnt >= TC_NGBMAX;
+                TC_STAGE_SWITCH(ST_EPILOGUE, ST_TEST);
+                if (!overflow) {
+                    if (dcnt > 0) { pad_stage((uint32_t)i, dcnt); convert_d(F); }
+                    if (wcnt > 0) convert_w(F, wcnt);
+                }
+                TC_STAGE_SWITCH(ST_TEST, ST_EPILOGUE);
+            };
+            if (wrap) run_it(std::false_type());
+            else run_it(tc_tag_ord());
+        } else if (!ord && fast) {
             const std::true_type F;
             d.ncand += stream_rows_q<true>(k, q, xi, yi, zi, idx,
                                            [&](uint32_t j, float4 p, bool act) { return gather(F, j, p, act); } TC_PROF_PASS);
@@ -2324,7 +2546,11 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         const int ca = cs + co;
 
         if (!overflow) {
-            if (do_wvt && cw < TC_NGBMAX) {
+            if (ord) {
+                /* a list in index order exists only if the runs fed the gather, the reference's list would not have
+                 * been cut (src/tree.c:91-92) and everything fitted */
+                wvt_done = nxr != TC_XNONE && cw < TC_NGBMAX && cwout <= TC_XLCAP;
+            } else if (do_wvt && cw < TC_NGBMAX) {
                 wsum2(u0, u1, u0, u1); u2 = wsum(u2);
                 wvt_done = true;
             }
@@ -2364,7 +2590,12 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     }
     if (finite) density_store<STATS>(da, i, d);
 
-    if (do_wvt) {
+    if (ord) {
+        if (lane == 0) {
+            a.xlcnt[i] = wvt_done ? (uint32_t)cwout : TC_XNONE;
+            if (!wvt_done) a.xun[atomicAdd(a.xun_cnt, 1)] = (uint32_t)i;       /* not listed: k_wvt_exact4 takes the particle */
+        }
+    } else if (do_wvt) {
         if (!wvt_done) {
             const tc_dev_const kv = particle_view(da.k, da.hsml_in[i], pi.w);
             wvt_sum(kv, i, pi, (double)pi.w, da.flags, idx, TC_ITER_IDXCAP, sw, u0, u1, u2);
@@ -2387,7 +2618,7 @@ extern "C" int tcgpu_debug_stage_cycles(uint32_t *out, int nwaves)
 }
 #endif
 
-template <bool STATS, bool WVT>
+template <bool STATS, int WVT>
 __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
 {
     __shared__ __align__(16) unsigned char lds_raw[WPB * TC_LDS_PER_WAVE_ITER];
@@ -2417,6 +2648,62 @@ __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
 #endif
 }
 
+/* Prepass of the ordered gather (WVT == 2): the index runs of the cells each particle's gather ball overlaps, in curve
+ * order (ordered_runs_pf, one lane per particle), transposed into the particle's own list xr[i * TC_XRCAP ...] so that
+ * the wavefront that later solves the particle reads them with one coalesced load.  Radius and level are the query
+ * record's (k_prec): the ball k_iter gathers, R = max(1.23 hsml, hsml_wvt box). */
+__global__ __launch_bounds__(TBN) void k_xruns(tc_dev_const k, const tc_prec *__restrict__ prec, const uint32_t *__restrict__ pf,
+                                               int pf_lmin, uint2 *__restrict__ scratch, uint2 *__restrict__ xr,
+                                               uint32_t *__restrict__ xrn, int *__restrict__ flags)
+{
+    __shared__ uint32_t lds_stk[WPB * (TC_MAX_LEVEL + 1) * 64];
+    __shared__ uint64_t lds_inv64[TC_HILBERT_NSTATES];
+    __shared__ unsigned char lds_perm[TC_HILBERT_NSTATES * 256];
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES; t += TBN) {
+        uint64_t r = 0;
+        for (int kk = 0; kk < 8; kk++) r |= (uint64_t)TC_HILBERT_INV[t * 8 + kk] << (8 * kk);
+        lds_inv64[t] = r;
+    }
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES * 256; t += TBN) {
+        const int stt = t >> 8, msk = t & 255;
+        uint32_t cm = 0;
+        for (int kk = 0; kk < 8; kk++) cm |= ((msk >> (TC_HILBERT_INV[stt * 8 + kk] & 7)) & 1u) << kk;
+        lds_perm[t] = (unsigned char)cm;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    uint32_t *stk = lds_stk + (size_t)wave * (TC_MAX_LEVEL + 1) * 64 + lane;
+    uint2 *wruns = scratch + (size_t)(blockIdx.x * WPB + wave) * ((size_t)TC_XRUNCAP * 64);
+    work_queue64(k, [&](int base, int stop) {
+        const int t = base + lane;
+        const bool valid = t < stop;
+        const int tt = valid ? t : base;
+        const int i = k.own ? (int)k.own[tt] : tt;
+        const float4 pi = k.pos4[i];
+        const tc_prec P = prec[i];
+        const uint32_t pfl = (P.pack >> 4) & 0x7fu;
+        const bool use = valid && (pfl & TC_PREC_VALID) && (pfl & TC_PREC_WARM);
+        const int Lq = (int)(P.pack & 15u);
+        int nr = ordered_runs_pf(k, pf, pf_lmin, use, pi.x, pi.y, pi.z, P.R, Lq > 0 ? Lq : 1, lds_inv64, lds_perm, stk,
+                                 wruns + lane, flags);
+        if (valid) xrn[i] = (use && nr <= TC_XRCAP) ? (uint32_t)nr : TC_XNONE;
+        /* the runs were written one lane per particle ([slot][lane]); each particle's list is now copied out by the
+         * whole wave, coalesced */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int pl = 0; pl < 64 && base + pl < stop; pl++) {
+            const int np = __shfl(nr, pl);
+            const bool up = __shfl((int)use, pl) != 0;
+            if (!up || np > TC_XRCAP) continue;
+            const int ip = __shfl(i, pl);
+            for (int q = lane; q < np; q += 64) xr[(size_t)ip * TC_XRCAP + q] = wruns[(size_t)q * 64 + pl];
+        }
+    });
+}
+
+/* with_wvt: 0 density only; 1 + round 2's f64 sweep sums (ustep); 2 + the sweep's neighbours listed in index order
+ * (xlist / xlcnt, for k_wvt_chain4) with the gather fed from ordered runs */
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
 {
     tc_iter_args a;
@@ -2431,19 +2718,47 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     a.d.flags = c->flags;
     a.d.stats = c->want_stats ? c->stats : nullptr;
     a.d.stats_stride = (int)c->cap;
-    a.ustep = with_wvt ? c->ustep : nullptr;
-    TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
+    a.ustep = with_wvt == 1 ? c->ustep : nullptr;
+    a.xr = nullptr; a.xrn = nullptr; a.xlist = nullptr; a.xlcnt = nullptr; a.xun = nullptr; a.xun_cnt = nullptr;
     int nloc = a.d.k.hi - a.d.k.lo;
     if (nloc <= 0) return 0;
     if (!c->prec) TC_HIP(c, hipMalloc(&c->prec, (size_t)c->cap * sizeof(tc_prec)));
     a.prec = (const tc_prec *)c->prec;
     tc_phase_begin(c, PH_PREC);
-    k_prec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a.d.k, a.d.hsml_in, with_wvt, c->no_records, (tc_prec *)c->prec);
+    k_prec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a.d.k, a.d.hsml_in, with_wvt != 0, c->no_records, (tc_prec *)c->prec);
+    if (with_wvt == 2) {
+        /* run lists and neighbour lists of every local slot (own particles use theirs) */
+        const size_t cap = (size_t)c->cap;
+        if (c->xr_cap < cap) {
+            hipFree(c->xr); hipFree(c->xrn); hipFree(c->xlist); hipFree(c->xlcnt); hipFree(c->xun);
+            c->xr = nullptr; c->xrn = nullptr; c->xlist = nullptr; c->xlcnt = nullptr; c->xun = nullptr; c->xr_cap = 0;
+            TC_HIP(c, hipMalloc(&c->xr, cap * TC_XRCAP * sizeof(uint2)));
+            TC_HIP(c, hipMalloc(&c->xrn, cap * sizeof(uint32_t)));
+            TC_HIP(c, hipMalloc(&c->xlist, cap * TC_XLCAP * sizeof(uint32_t)));
+            TC_HIP(c, hipMalloc(&c->xlcnt, cap * sizeof(uint32_t)));
+            TC_HIP(c, hipMalloc(&c->xun, (cap + 4) * sizeof(uint32_t)));           /* the count lives behind the list */
+            c->xr_cap = cap;
+        }
+        const int gx = xgrid(c, nloc, k_xruns);
+        const size_t want = (size_t)gx * WPB * TC_XRUNCAP * 64 * sizeof(uint2);
+        if (c->xruns_bytes < want) {
+            if (c->xruns) TC_HIP(c, hipFree(c->xruns));
+            c->xruns = nullptr; c->xruns_bytes = 0;
+            TC_HIP(c, hipMalloc(&c->xruns, want));
+            c->xruns_bytes = want;
+        }
+        TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
+        k_xruns<<<gx, TBN, 0, c->stream>>>(a.d.k, a.prec, c->pf, c->pf_lmin, (uint2 *)c->xruns, (uint2 *)c->xr, c->xrn, c->flags);
+        a.xr = (const uint2 *)c->xr; a.xrn = c->xrn; a.xlist = c->xlist; a.xlcnt = c->xlcnt;
+        a.xun = c->xun; a.xun_cnt = (int *)(c->xun + c->xr_cap);
+        TC_HIP(c, hipMemsetAsync(a.xun_cnt, 0, sizeof(int), c->stream));
+    }
     tc_phase_end(c);
+    TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     tc_phase_begin(c, PH_DENSITY);
 #define TC_LAUNCH_ITER(S, W) k_iter<S, W><<<grid_for(c, nloc, k_iter<S, W>), TBN, 0, c->stream>>>(a)
-    if (a.d.stats) { if (with_wvt) TC_LAUNCH_ITER(true, true); else TC_LAUNCH_ITER(true, false); }
-    else { if (with_wvt) TC_LAUNCH_ITER(false, true); else TC_LAUNCH_ITER(false, false); }
+    if (a.d.stats) { if (with_wvt == 2) TC_LAUNCH_ITER(true, 2); else if (with_wvt) TC_LAUNCH_ITER(true, 1); else TC_LAUNCH_ITER(true, 0); }
+    else { if (with_wvt == 2) TC_LAUNCH_ITER(false, 2); else if (with_wvt) TC_LAUNCH_ITER(false, 1); else TC_LAUNCH_ITER(false, 0); }
 #undef TC_LAUNCH_ITER
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());

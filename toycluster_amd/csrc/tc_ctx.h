@@ -19,6 +19,9 @@
 #define TC_STAGE 128             /* ring of staged hit positions per wave (power of two, >= 128) */
 #define TC_SMALLCELL 64          /* cells up to this size are expanded one lane per cell */
 #define TC_MAX_PERSISTENT_BLOCKS 2048
+#define TC_XRCAP 128             /* ordered index runs per particle handed to k_iter (k_xruns); more: the plain paths */
+#define TC_XLCAP 448             /* sweep neighbours per particle handed to k_wvt_chain4; more: k_wvt_exact4 does that particle */
+#define TC_XNONE 0xffffffffu     /* xlcnt / xrn: no list for this particle */
 
 enum tc_phase {
     PH_KEYS = 0, PH_SORT, PH_PERMUTE, PH_CELLS, PH_GUESS, PH_DENSITY, PH_ERROR, PH_MODEL_HSML,
@@ -59,6 +62,7 @@ struct tc_dev_const {
     const uint32_t *mirror_idx;   /* slot -> Peano index */
     int lmax_rm, lmin_rm;         /* mirrored levels: lmin_rm..lmax_rm */
     uint32_t mirror_pad;          /* slot holding a position at infinity (padding lanes load it) */
+    uint32_t pos_pad;             /* ... and the like slot of pos4 (index cap) */
     int n;                        /* particles of the local set (neighbour candidates) */
     int lo, hi;                   /* work items [lo,hi): particle own[t] (own != NULL) or t itself */
     const uint32_t *own;          /* sharded contexts: local indices of the particles this GPU solves, ascending */
@@ -207,7 +211,8 @@ struct tcgpu_ctx {
     float *rhom_next;             /* cap: model density at the current positions, committed by the sweep (G order) */
     int ustep_valid;              /* ustep belongs to the current local order and positions */
     int fuse;                     /* option: use the fused kernel (default 1) */
-    int sweep_mode;               /* option "sweep": 0 = the reference's f32 accumulation in ascending index (k_wvt_exact, default),
+    int sweep_mode;               /* option "sweep": 0 = the reference's f32 accumulation in ascending index, the neighbours listed
+                                   * by k_iter on the way (default); 2 = the same sums by the stand-alone k_wvt_exact4;
                                    * 1 = round 2's f64 sums rounded once (fused into k_iter, or k_wvt) */
     int xsweep_shift;             /* option "xsweep_shift": added to the query level of k_wvt_exact (tuning) */
     int xsweep_kernel;            /* option "xsweep_kernel" (tests): 1 = the one-lane-per-particle kernel for every launch */
@@ -215,6 +220,11 @@ struct tcgpu_ctx {
     void *pf_tmp;
     size_t pf_alloc, pf_tmp_bytes;
     int pf_lmin, pf_valid;        /* ... built for the current local order */
+    void *xr; uint32_t *xrn;      /* per-particle ordered run lists of the gather (k_xruns) and their lengths; on demand */
+    uint32_t *xlist, *xlcnt;      /* per-particle sweep neighbours in index order, written by k_iter (WVT == 2) */
+    uint32_t *xun;                /* particles k_iter could not list (+ their count at [xr_cap]) */
+    size_t xr_cap;
+    int xlist_valid;              /* ... belong to the current local order, positions and model hsml */
     void *xruns;                  /* per-wave index runs of k_wvt_exact, on demand */
     size_t xruns_bytes;
     int num_cu;
