@@ -2133,6 +2133,141 @@ __global__ __launch_bounds__(TBN) void k_wvt_chain4(tc_xwvt_args a)
     });
 }
 
+/* The same sweep for the FEW particles k_iter could not list (more neighbours than a list holds, a cut list, no record):
+ * one WAVEFRONT per particle.  Throughput is poor -- the f32 chain keeps three lanes busy for a thousand dependent
+ * additions -- but latency is what counts for a handful of particles behind 2e6 others: a group of k_wvt_exact4 needs a
+ * millisecond whatever its size, a wavefront here ~0.1 ms.  Lane 0 walks the cells in curve order (ordered_runs_pf), the wave
+ * streams the runs (stream_runs), hits are compacted in index order 64 at a time, their terms evaluated lane-parallel
+ * (src/wvt_relax.c:141-169, the arithmetic of k_wvt_exact4) and added in order by lanes 0..2 (x, y, z). */
+__global__ __launch_bounds__(TBN) void k_wvt_exact_w(tc_xwvt_args a)
+{
+    __shared__ uint32_t lds_heads[WPB * 256];
+    __shared__ __align__(16) float4 lds_ring[WPB * 128];
+    __shared__ double lds_term[WPB * 64 * 3];
+    __shared__ uint32_t lds_stk[WPB * (TC_MAX_LEVEL + 1) * 64];
+    __shared__ uint2 lds_dense[WPB * TC_XRUNCAP];
+    __shared__ uint64_t lds_inv64[TC_HILBERT_NSTATES];
+    __shared__ unsigned char lds_perm[TC_HILBERT_NSTATES * 256];
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES; t += TBN) {
+        uint64_t r = 0;
+        for (int kk = 0; kk < 8; kk++) r |= (uint64_t)TC_HILBERT_INV[t * 8 + kk] << (8 * kk);
+        lds_inv64[t] = r;
+    }
+    for (int t = threadIdx.x; t < TC_HILBERT_NSTATES * 256; t += TBN) {
+        const int stt = t >> 8, msk = t & 255;
+        uint32_t cm = 0;
+        for (int kk = 0; kk < 8; kk++) cm |= ((msk >> (TC_HILBERT_INV[stt * 8 + kk] & 7)) & 1u) << kk;
+        lds_perm[t] = (unsigned char)cm;
+    }
+    __syncthreads();
+    tc_dev_const kw = a.k;
+    if (a.wl) { kw.lo = 0; kw.hi = *a.wl_cnt; kw.own = a.wl; }
+    const tc_dev_const &k = kw;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    uint2 *dense = lds_dense + (size_t)wave * TC_XRUNCAP;
+    uint32_t *heads = lds_heads + wave * 256;
+    float4 *ring = lds_ring + wave * 128;
+    double *term = lds_term + wave * 192;
+    uint32_t *stk = lds_stk + (size_t)wave * (TC_MAX_LEVEL + 1) * 64 + lane;
+    uint2 *wruns = a.runs + (size_t)(blockIdx.x * WPB + wave) * ((size_t)TC_XRUNCAP * 64);
+    const double boxinv = k.boxinv;
+    work_queue(k, [&](int i) {
+        const float4 pv = k.pos4[i];
+        const float4 pi = make_float4(U(pv.x), U(pv.y), U(pv.z), U(pv.w));
+        const float xi = pi.x, yi = pi.y, zi = pi.z;
+        const float hq = (float)((double)pi.w * k.boxsize);             /* src/wvt_relax.c:135 */
+        const float hq2 = hq * hq;
+        int lmin = k.lmin_tab, lmaxp = k.lmax;
+        if (k.margin_on) {
+            const float h0 = a.hsml0[i];
+            const float rg = tc_margin_radius(h0, pi.w, k.boxsize, k.margin_widen);
+            tc_particle_levels(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift, k.lmax, h0, rg, &lmin, &lmaxp);
+        }
+        const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
+        /* lane 0 alone walks the cells: its runs land at wruns[64 s] */
+        int nruns = ordered_runs_pf(k, a.pf, a.pf_lmin, lane == 0, xi, yi, zi, hq, Lq, lds_inv64, lds_perm, stk, wruns, a.flags);
+        nruns = U(nruns);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        /* ... and are repacked densely (LDS) for the streaming */
+        wave_lds_fence();
+        for (int q = lane; q < nruns; q += 64) dense[q] = wruns[(size_t)q * 64];
+        wave_lds_fence();
+
+        const double ext = (double)hq * (1.0 + 1e-5) + k.boxsize * 1e-5;
+        const bool wrap = !((double)xi >= ext && (double)xi <= k.boxsize - ext && (double)yi >= ext
+                            && (double)yi <= k.boxsize - ext && (double)zi >= ext && (double)zi <= k.boxsize - ext);
+        const double step_hi = a.step * (double)pi.w;                   /* step * hsml[ipart], src/wvt_relax.c:167 */
+        float dacc = 0;                                                 /* lane c < 3: delta[c] */
+        int nlist = 0, scnt = 0, head = 0;
+        /* 64 staged neighbours (ring, index order): their terms lane-parallel, then the ordered chain */
+        auto convert = [&](int nvalid) {
+            wave_lds_fence();
+            const float4 pj = ring[(head + lane) & 127];
+            float dx = (float)((double)(xi - pj.x) * boxinv);
+            float dy = (float)((double)(yi - pj.y) * boxinv);
+            float dz = (float)((double)(zi - pj.z) * boxinv);
+            if (wrap) {
+                dx = dx > 0.5f ? dx - 1.0f : dx;                        /* src/wvt_relax.c:148-154 (0.5 is exact in f32) */
+                dy = dy > 0.5f ? dy - 1.0f : dy;
+                dz = dz > 0.5f ? dz - 1.0f : dz;
+                dx = dx < -0.5f ? dx + 1.0f : dx;
+                dy = dy < -0.5f ? dy + 1.0f : dy;
+                dz = dz < -0.5f ? dz + 1.0f : dz;
+            }
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            const float h = (float)(0.5 * (double)(pi.w + pj.w));
+            const bool in = lane < nvalid && !(r2 > h * h);
+            double e0 = 0, e1 = 0, e2 = 0;
+            if (in) {
+                if (r2 < 1e-24f) {                                      /* coincident particles: the IEEE sequences */
+                    const float r = sqrtf(r2);
+                    const float wk = (float)tc_wvt_wc6(r, h);
+                    e0 = step_hi * (double)wk * (double)dx / (double)r;
+                    e1 = step_hi * (double)wk * (double)dy / (double)r;
+                    e2 = step_hi * (double)wk * (double)dz / (double)r;
+                } else {
+                    const float r = tc_sqrt_f32_lean_pos(r2);
+                    const double u = (double)tc_div_f32_lean(r, h);
+                    const double t1 = 1 - u;
+                    const float wk = (float)(TC_WC6_NORM * t1 * t1 * t1 * t1 * t1 * t1 * t1 * t1
+                                             * (1 + 8 * u + 25 * u * u + 32 * u * u * u));
+                    const double b = step_hi * (double)wk;
+                    e0 = tc_div_f64_lean(b * (double)dx, (double)r);
+                    e1 = tc_div_f64_lean(b * (double)dy, (double)r);
+                    e2 = tc_div_f64_lean(b * (double)dz, (double)r);
+                }
+            }
+            term[3 * lane] = e0; term[3 * lane + 1] = e1; term[3 * lane + 2] = e2;
+            wave_lds_fence();
+            if (lane < 3)
+                for (int q = 0; q < nvalid; q++) dacc = (float)((double)dacc + term[3 * q + lane]);   /* src/wvt_relax.c:167-169 */
+            head = U((head + 64) & 127);
+            wave_lds_fence();
+        };
+        bool cut = false;
+        stream_runs(k, dense, nruns, heads, [&](uint32_t j, float4 p, bool act) -> bool {
+            const float4 pf4 = k.pos4[j < (uint32_t)k.n ? j : (uint32_t)i];           /* w (hsml_j) too: the stream loads x, y, z */
+            const float r2 = ngb_r2_w(xi, yi, zi, p.x, p.y, p.z, k.boxhalf_f, k.boxsize_f, wrap);
+            const bool hit = act && r2 < hq2;
+            const uint64_t mh = tc_ballot(hit);
+            /* the reference's list ends at its NGBMAX-th entry (src/tree.c:91-92); the particle itself is on it, not in the sum */
+            const bool keep = hit && nlist + mask_rank(mh) < TC_NGBMAX && j != (uint32_t)i;
+            const uint64_t mk = tc_ballot(keep);
+            if (keep) ring[(head + scnt + mask_rank(mk)) & 127] = pf4;
+            scnt = U(scnt + (int)__popcll(mk));
+            nlist = U(nlist + (int)__popcll(mh));
+            if (scnt >= 64) { convert(64); scnt = U(scnt - 64); }
+            if (nlist >= TC_NGBMAX) { cut = true; return true; }
+            return false;
+        });
+        if (scnt > 0) convert(scnt);
+        if (cut && lane == 0) atomicAdd(&a.flags[4], 1);
+        if (lane < 3) a.delta[3 * (size_t)a.lg[i] + lane] = dacc;
+    });
+}
+
 template <class K>
 static int xgrid(const tcgpu_ctx *c, int nloc, K kernel)
 {
@@ -2166,7 +2301,11 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
     const int g4 = xgrid(c, nloc, k_wvt_exact4), g1 = xgrid(c, nloc, k_wvt_exact);
-    const size_t want = (size_t)(g4 > g1 ? g4 : g1) * WPB * TC_XRUNCAP * 64 * sizeof(uint2);
+    int gw = grid_for(c, nloc, k_wvt_exact_w);
+    if (gw > 1024) gw = 1024;
+    int gm = g4 > g1 ? g4 : g1;
+    if (gw > gm) gm = gw;
+    const size_t want = (size_t)gm * WPB * TC_XRUNCAP * 64 * sizeof(uint2);
     if (c->xruns_bytes < want) {
         if (c->xruns) TC_HIP(c, hipFree(c->xruns));
         c->xruns = nullptr; c->xruns_bytes = 0;
@@ -2188,7 +2327,8 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
      * tiles of the index space -- was tried in round 3 and dropped: the Peano runs of a ball are short and scattered, a
      * group of 64 particles touches hundreds of 128-particle tiles: 26 ms.) */
     if (c->xsweep_kernel == 1) k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
-    else k_wvt_exact4<<<lists && g4 > 512 ? 512 : g4, TBN, 0, c->stream>>>(a);      /* lists: only the few particles without one */
+    else if (lists) k_wvt_exact_w<<<gw, TBN, 0, c->stream>>>(a);      /* only the few particles without a list: a wavefront each */
+    else k_wvt_exact4<<<g4, TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());
     return 0;
