@@ -1097,6 +1097,19 @@ static int density_stats(tcgpu_ctx *c)
     return 0;
 }
 
+/* The ordered gather keeps a run list (TC_XRCAP x 8 B) and a neighbour list (TC_XLCAP x 4 B) per local slot: 2.8 KB per
+ * particle, 5.7 GB at 2e6, 45 GB at 1.6e7 -- and 283 GB at 1e8, which one GPU does not have next to everything else.
+ * Lists are used when they take at most 40 % of the device's memory and fit into what is free; otherwise the sweep runs
+ * stand-alone (k_wvt_exact4: same sums, 4 ms more per 2e6 particles).  Sharded ranks hold 1/R of the particles each. */
+static bool xlists_fit(tcgpu_ctx *c)
+{
+    if (c->xr_cap >= (size_t)c->cap) return true;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    const double need = (double)c->cap * (TC_XRCAP * 8.0 + TC_XLCAP * 4.0 + 12.0);
+    return need <= 0.4 * (double)tot && need + 4e9 <= (double)fr;
+}
+
 /* One density pass (src/sph.c:13-72) up to, not including, the write-back of the results: local set, sort, index,
  * first-pass guess, solve.  `full` forces the whole set as local set. */
 static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int full)
@@ -1113,7 +1126,8 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
          * follows on the same positions */
         /* the sweep rides along only in round 2's mode (f64 sums, one rounding); the default sweep reproduces the
          * reference's order and roundings in a kernel of its own (k_wvt_exact), after the step is known */
-        const int ride = !with_wvt ? 0 : c->sweep_mode == 1 ? 1 : (c->sweep_mode == 0 && !c->xsweep_kernel) ? 2 : 0;
+        int ride = !with_wvt ? 0 : c->sweep_mode == 1 ? 1 : (c->sweep_mode == 0 && !c->xsweep_kernel) ? 2 : 0;
+        if (ride == 2 && !xlists_fit(c)) ride = 0;          /* too many particles for per-particle lists: the stand-alone sweep */
         if (ride == 2) {                                                            /* the ordered runs come from pf; */
             if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;              /* nobody needs the mirror */
         } else if ((rc = tc_launch_mirror(c))) return rc;

@@ -2548,7 +2548,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             int sl = (whead + lane) & (TC_STAGE - 1);
             if (ord) {
                 /* the neighbours reach this point in ascending index: 64 more entries of the particle's list */
-                if (lane < nvalid && cwout + lane < TC_XLCAP) a.xlist[(size_t)i * TC_XLCAP + cwout + lane] = wj[sl];
+                if (lane < nvalid && cwout + lane < TC_XLCAP)      /* streamed out: not to displace the positions in L2 */
+                    __builtin_nontemporal_store(wj[sl], &a.xlist[(size_t)i * TC_XLCAP + cwout + lane]);
                 cwout = U(cwout + nvalid);
             } else {
             const float4 p = MIR ? ld4(vmirror, lane < nvalid ? wj[sl] : 0u) : k.pos4[lane < nvalid ? wj[sl] : (uint32_t)i];

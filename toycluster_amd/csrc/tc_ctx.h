@@ -19,7 +19,7 @@
 #define TC_STAGE 128             /* ring of staged hit positions per wave (power of two, >= 128) */
 #define TC_SMALLCELL 64          /* cells up to this size are expanded one lane per cell */
 #define TC_MAX_PERSISTENT_BLOCKS 2048
-#define TC_XRCAP 128             /* ordered index runs per particle handed to k_iter (k_xruns); more: the plain paths */
+#define TC_XRCAP 96              /* ordered index runs per particle handed to k_iter (k_xruns; mean 29, max 78 at 2e6); more: the plain paths */
 #define TC_XLCAP 448             /* sweep neighbours per particle handed to k_wvt_chain4; more: k_wvt_exact4 does that particle */
 #define TC_XNONE 0xffffffffu     /* xlcnt / xrn: no list for this particle */
 
