@@ -13,9 +13,10 @@ Weak scaling: 2e6 particles per GPU; every rank solves its contiguous Peano rang
 exchange positions / smoothing lengths with RCCL all-gathers each iteration.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     -- dominant kernel (k_iter = hsml / density solve): counted vector flops / measured kernel time vs the
-                  f64 vector peak (the kernel is VALU-bound), HBM figure beside it; the second
-                  kernel of the step (k_wvt_exact4, the sweep in the reference's summation order) in `sweep_kernel`
+  roofline     -- dominant kernel (k_iter = hsml / density solve; it also lists the sweep's neighbours in index order):
+                  counted vector flops / measured kernel time vs the f64 vector peak (the kernel is VALU-bound; DESIGN.md
+                  section 4), HBM figure beside it; the sweep's own kernels (k_wvt_chain4: the lists evaluated in the
+                  reference's summation order) in `sweep_kernel`
   cpu_baseline -- the CPU oracle ("port" of the reference algorithm, OpenMP) on the SAME workload and state:
                   warm WVT iterations started from the GPU's positions and smoothing lengths
 """
@@ -89,8 +90,9 @@ def main():
                     help="profiling runs: skip the stats pass and the whole-relaxation run behind the timed steps")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--sweep", type=int, default=0,
-                    help="0: the sweep in the reference's summation order (default, what the library does); 1: round 2's "
-                         "fused f64 sweep (faster, ~1e-6 |delta| off per iteration) -- for A/B runs only")
+                    help="0: the sweep in the reference's summation order, neighbour lists from k_iter (default, what the "
+                         "library does); 2: the same sums by the stand-alone kernel; 1: round 2's fused f64 sweep (faster, "
+                         "~1e-6 |delta| off per iteration) -- 1 and 2 for A/B runs only")
     ap.add_argument("--force-comm", action="store_true",
                     help="testing: run the RCCL collectives through a 1-rank communicator")
     ap.add_argument("--force-dist", action="store_true",
@@ -125,7 +127,7 @@ def main():
 
     opts = {}
     if args.force_comm: opts["force_comm"] = 1
-    if args.sweep: opts["sweep"] = 1
+    if args.sweep: opts["sweep"] = args.sweep
     g = binding.TcGpu(local_rank, rank=rank, nranks=world, unique_id=uid, options=opts or None)
     g.set_model(m)
     g.upload(pos, ids)
@@ -189,9 +191,9 @@ def main():
         g.density_error()
         st = g.density_stats()
         g.set_option("stats", 0)
-    flop_per_particle = st["pair_evals"] * FLOP_PER_SOLVER_PAIR + (FLOP_SWEEP_PER_PARTICLE if args.sweep else 0.0)
+    flop_per_particle = st["pair_evals"] * FLOP_PER_SOLVER_PAIR + (FLOP_SWEEP_PER_PARTICLE if args.sweep == 1 else 0.0)
     tflops = flop_per_particle * n_local / dens_avg / 1e12 if dens_avg > 0 else 0.0
-    sweep_tflops = FLOP_SWEEP_PER_PARTICLE * n_local / sw_avg / 1e12 if (sw_avg > 0 and not args.sweep) else 0.0
+    sweep_tflops = FLOP_SWEEP_PER_PARTICLE * n_local / sw_avg / 1e12 if (sw_avg > 0 and args.sweep != 1) else 0.0
 
     # One whole relaxation under the reference's stop rule (wvt_relax.c:94-98) from the same initial positions:
     # the second half of BASELINE.json's metric ("iterations to <1% rho-error" = stop-rule count).
@@ -259,26 +261,32 @@ def main():
                                       "sort / cell table / mirror; per iteration the ghost exchange over RCCL (interest pyramids "
                                       "all-gathered, 20 B per ghost sent to the ranks that need it) and two exact scalar "
                                       "all-reduces" % world,
-                       "sweep": ("reference order and roundings (k_wvt_exact4)" if not args.sweep else "round 2's fused f64 sweep (option sweep = 1)"),
+                       "sweep": {0: "reference order and roundings; neighbour lists in index order from k_iter, evaluated by k_wvt_chain4",
+                                 2: "reference order and roundings, stand-alone kernel k_wvt_exact4 (option sweep = 2)",
+                                 1: "round 2's fused f64 sweep (option sweep = 1)"}[args.sweep],
                        "ranks": per_rank,
                        "err_mean_last": errs[-1][0], "err_max_last": errs[-1][1]},
             # k_iter is a gather/stencil kernel bound by the vector ALU, not by HBM: the
             # headline fraction is counted vector flops against the f64 vector peak; the HBM fraction of its
             # compulsory 56 B/particle is reported beside it.
-            "roofline": {"bound": "valu", "kernel": "k_iter (hsml / density solve K5%s)" % (" + fused f64 sweep K9" if args.sweep else ""),
+            "roofline": {"bound": "valu", "kernel": "k_iter (hsml / density solve K5%s)" % (
+                             " + fused f64 sweep K9" if args.sweep == 1 else
+                             "; candidates from per-particle ordered runs, sweep neighbours listed on the way" if args.sweep == 0 else ""),
                          "achieved": tflops, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / F64_VECTOR_PEAK_TFLOPS,
                          "flop_model": "counted solver list visits/particle (stats pass of this run) x %g flop (SURVEY.md 8d), "
-                                       "all counted as f64%s" % (FLOP_PER_SOLVER_PAIR, " + %g flop for the fused sweep" % FLOP_SWEEP_PER_PARTICLE if args.sweep else ""),
+                                       "all counted as f64%s" % (FLOP_PER_SOLVER_PAIR, " + %g flop for the fused sweep" % FLOP_SWEEP_PER_PARTICLE if args.sweep == 1 else ""),
                          "solver_pair_evals_per_particle": st["pair_evals"], "queries_per_particle": st["queries"],
                          "candidates_per_particle": st["candidates"], "flop_per_particle": flop_per_particle,
                          "avg_launch_ms": 1e3 * dens_avg, "launches": dens_launch,
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_particle": BYTES_DENSITY_PER_PARTICLE,
                                  "whole_iteration_GBs": BYTES_ITER_PER_PARTICLE * n_total * args.steps / dt / 1e9 / world},
-                         "sweep_kernel": (None if args.sweep else
-                                          {"kernel": "k_wvt_exact4 (WVT sweep K9 in the reference's summation order: f32 accumulator, "
+                         "sweep_kernel": (None if args.sweep == 1 else
+                                          {"kernel": ("k_wvt_chain4 + k_wvt_exact_w" if args.sweep == 0 else "k_wvt_exact4") +
+                                                     " (WVT sweep K9 in the reference's summation order: f32 accumulator, "
                                                      "ascending index, one rounding per neighbour)",
+                                           "run_list_prepass_ms": mine["phase_ms_per_step"].get("query_records"),
                                            "avg_launch_ms": 1e3 * sw_avg, "launches": sw_launch, "bound": "valu",
                                            "achieved": sweep_tflops, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                            "frac": sweep_tflops / F64_VECTOR_PEAK_TFLOPS,
