@@ -1100,14 +1100,17 @@ static int density_stats(tcgpu_ctx *c)
 /* The ordered gather keeps a run list (TC_XRCAP x 8 B) and a neighbour list (TC_XLCAP x 4 B) per local slot: 2.8 KB per
  * particle, 5.7 GB at 2e6, 45 GB at 1.6e7 -- and 283 GB at 1e8, which one GPU does not have next to everything else.
  * Lists are used when they take at most 40 % of the device's memory and fit into what is free; otherwise the sweep runs
- * stand-alone (k_wvt_exact4: same sums, 4 ms more per 2e6 particles).  Sharded ranks hold 1/R of the particles each. */
+ * stand-alone (k_wvt_exact4: same sums, 4 ms more per 2e6 particles).  They are sized by the LOCAL SET of the pass: a
+ * sharded rank in steady state (own range + ghost shell, 1.4-1.9 x N / R) has room for them where the full set has not. */
 static bool xlists_fit(tcgpu_ctx *c)
 {
-    if (c->xr_cap >= (size_t)c->cap) return true;
+    if (c->xr_cap >= (size_t)c->nloc) return true;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
-    const double need = (double)c->cap * (TC_XRCAP * 8.0 + TC_XLCAP * 4.0 + 12.0);
-    return need <= 0.4 * (double)tot && need + 4e9 <= (double)fr;
+    const double per = TC_XRCAP * 8.0 + TC_XLCAP * 4.0 + 12.0;
+    const double need = ((double)c->nloc * 1.125 + 1024) * per;
+    const double have = (double)c->xr_cap * per;                   /* freed when the lists grow */
+    return need <= 0.4 * (double)tot && need + 4e9 <= (double)fr + have;
 }
 
 /* One density pass (src/sph.c:13-72) up to, not including, the write-back of the results: local set, sort, index,

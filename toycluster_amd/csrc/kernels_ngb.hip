@@ -2869,8 +2869,11 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     k_prec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a.d.k, a.d.hsml_in, with_wvt != 0, c->no_records, (tc_prec *)c->prec);
     if (with_wvt == 2) {
         /* run lists and neighbour lists of every local slot (own particles use theirs) */
-        const size_t cap = (size_t)c->cap;
-        if (c->xr_cap < cap) {
+        /* sized by the local set of this pass (with head room), not by the particle capacity: on a sharded rank the local
+         * set is a fraction of everything, and the lists are what takes the memory (xlists_fit, api.hip) */
+        size_t cap = (size_t)c->nloc + (size_t)c->nloc / 8 + 1024;
+        if (cap > (size_t)c->cap) cap = (size_t)c->cap;
+        if (c->xr_cap < (size_t)c->nloc) {
             hipFree(c->xr); hipFree(c->xrn); hipFree(c->xlist); hipFree(c->xlcnt); hipFree(c->xun);
             c->xr = nullptr; c->xrn = nullptr; c->xlist = nullptr; c->xlcnt = nullptr; c->xun = nullptr; c->xr_cap = 0;
             TC_HIP(c, hipMalloc(&c->xr, cap * TC_XRCAP * sizeof(uint2)));
