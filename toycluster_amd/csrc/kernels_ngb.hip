@@ -1692,9 +1692,12 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact(tc_xwvt_args a)
  * final: their key ranges (level-Lq keys) are noted in curve order, adjacent ones merged; the others are descended into,
  * one at a time (the node's state waits in a per-lane LDS stack).  Every iteration of the wave's loop is one visit of
  * one node per lane.  At the end the key ranges become index runs: [pf[a], pf[b + 1]).  Returns the number of runs. */
+/* `runs`: entry s of this lane's list at runs[s * stride], at most `cap` entries (a longer list is cut and its true length
+ * returned; with `flags` the overflow is also reported as an error). */
 __device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint32_t *pf, int pf_lmin, bool valid, float xi,
                                                float yi, float zi, float hq, int Lq, const uint64_t *inv64,
-                                               const unsigned char *perm, uint32_t *stk, uint2 *runs, int *flags)
+                                               const unsigned char *perm, uint32_t *stk, uint2 *runs, int *flags,
+                                               const int stride = 64, const int cap = TC_XRUNCAP)
 {
     const float boxf = k.boxsize_f, boxh = k.boxhalf_f;
     const float hp = (float)((double)hq * (1.0 + 1e-5) + k.boxsize * 4e-6);
@@ -1712,14 +1715,19 @@ __device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint
     auto emit = [&](uint32_t A, uint32_t B) {
         if (have && A == rb + 1u) rb = B;
         else {
-            if (have) { if (nout < TC_XRUNCAP) runs[(size_t)nout * 64] = make_uint2(ra, rb); nout++; }
+            if (have) { if (nout < cap) runs[(size_t)nout * stride] = make_uint2(ra, rb); nout++; }
             ra = A; rb = B; have = true;
         }
     };
+    /* Every turn of the wave's loop EVALUATES one node per lane (the expensive, uniform part); what follows -- noting the
+     * final children, opening the next partial one, or climbing back until there is one -- is cheap and of variable
+     * length.  (First version: a turn per visit, entered or resumed: twice the turns, and lanes out of phase paid the
+     * evaluation in every one of them.) */
+    (void)enter;
     while (tc_ballot(active)) {
         if (active) {
-            const float s = __builtin_ldexpf(boxf, -(l + 1));          /* edge of the children */
-            if (enter) {
+            {
+                const float s = __builtin_ldexpf(boxf, -(l + 1));      /* edge of the children */
                 /* periodic distance per dimension from the particle to the midpoint of the lower / upper child */
                 const float hs = 0.5f * s;
                 float g[6], f[6];                                    /* nearest / farthest distance, [2 d + half] */
@@ -1748,37 +1756,37 @@ __device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint
                 }
                 cov = perm[st * 256 + ov];
                 cfin = (l + 1 == Lq) ? cov : (uint32_t)perm[st * 256 + (in & ov)];
-                enter = false;
             }
-            /* final children ahead of the first one that has to be opened: note their key ranges */
-            const uint32_t part = cov & ~cfin;
-            const uint32_t upto = part ? (1u << __builtin_ctz(part)) - 1u : 0xffu;
-            uint32_t fn = cov & cfin & upto;
-            cov &= ~fn;
-            const int sh = 3 * (Lq - (l + 1));
-            while (fn) {
-                const int a0 = __builtin_ctz(fn);
-                const int len = __builtin_ctz(~(fn >> a0));
-                fn &= ~(((1u << len) - 1u) << a0);
-                const uint32_t A = ((key << 3) + (uint32_t)a0) << sh;
-                const uint32_t B = ((((key << 3) + (uint32_t)(a0 + len - 1)) + 1u) << sh) - 1u;
-                emit(A, B);
-            }
-            if (part) {                                              /* open the next child */
-                const int kk = __builtin_ctz(part);
-                cov &= ~(1u << kk);
-                stk[64 * l] = cov | (cfin << 8) | (st << 16);
-                const uint32_t e = (uint32_t)(inv64[st] >> (8 * kk)) & 0xffu;
-                cx = 2 * cx + (int)(e & 1u);
-                cy = 2 * cy + (int)((e >> 2) & 1u);
-                cz = 2 * cz + (int)((e >> 1) & 1u);
-                key = (key << 3) + (uint32_t)kk;
-                st = e >> 3;
-                l++;
-                enter = true;
-            } else if (l == 0) active = false;
-            else {                                                   /* node done: back to its parent */
-                l--;
+            for (;;) {
+                /* final children ahead of the first one that has to be opened: note their key ranges */
+                const uint32_t part = cov & ~cfin;
+                const uint32_t upto = part ? (1u << __builtin_ctz(part)) - 1u : 0xffu;
+                uint32_t fn = cov & cfin & upto;
+                cov &= ~fn;
+                const int sh = 3 * (Lq - (l + 1));
+                while (fn) {
+                    const int a0 = __builtin_ctz(fn);
+                    const int len = __builtin_ctz(~(fn >> a0));
+                    fn &= ~(((1u << len) - 1u) << a0);
+                    const uint32_t A = ((key << 3) + (uint32_t)a0) << sh;
+                    const uint32_t B = ((((key << 3) + (uint32_t)(a0 + len - 1)) + 1u) << sh) - 1u;
+                    emit(A, B);
+                }
+                if (part) {                                          /* open the next child: evaluated in the next turn */
+                    const int kk = __builtin_ctz(part);
+                    cov &= ~(1u << kk);
+                    stk[64 * l] = cov | (cfin << 8) | (st << 16);
+                    const uint32_t e = (uint32_t)(inv64[st] >> (8 * kk)) & 0xffu;
+                    cx = 2 * cx + (int)(e & 1u);
+                    cy = 2 * cy + (int)((e >> 2) & 1u);
+                    cz = 2 * cz + (int)((e >> 1) & 1u);
+                    key = (key << 3) + (uint32_t)kk;
+                    st = e >> 3;
+                    l++;
+                    break;
+                }
+                if (l == 0) { active = false; break; }
+                l--;                                                 /* node done: back to its parent, and look on there */
                 const uint32_t w = stk[64 * l];
                 key >>= 3;
                 cx >>= 1; cy >>= 1; cz >>= 1;
@@ -1786,8 +1794,9 @@ __device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint
             }
         }
     }
-    if (have) { if (nout < TC_XRUNCAP) runs[(size_t)nout * 64] = make_uint2(ra, rb); nout++; }
-    if (nout > TC_XRUNCAP) { atomicOr(&flags[3], 1); nout = TC_XRUNCAP; }
+    if (have) { if (nout < cap) runs[(size_t)nout * stride] = make_uint2(ra, rb); nout++; }
+    const int ntrue = nout;
+    if (nout > cap) { if (flags) atomicOr(&flags[3], 1); nout = cap; }
     /* key ranges -> index runs */
     uint32_t off = 0;
     for (int L = pf_lmin; L < Lq; L++) off += (1u << (3 * L)) + 1u;
@@ -1795,11 +1804,11 @@ __device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint
     const uint32_t bias = (uint32_t)(Lq - pf_lmin) * (uint32_t)(k.n + 1);
     int m = 0;
     for (int t = 0; t < nout; t++) {
-        const uint2 kr = runs[(size_t)t * 64];
+        const uint2 kr = runs[(size_t)t * stride];
         const uint32_t f0 = pfL[kr.x] - bias, e0 = pfL[kr.y + 1u] - bias;
-        if (e0 > f0) { runs[(size_t)m * 64] = make_uint2(f0, e0); m++; }
+        if (e0 > f0) { runs[(size_t)m * stride] = make_uint2(f0, e0); m++; }
     }
-    return m;
+    return ntrue > cap ? ntrue : m;
 }
 
 /* The same sweep with FOUR lanes per particle for the two phases that touch memory (the launch's normal kernel).
@@ -1880,8 +1889,8 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
             }
             const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
             wave_lds_fence();                                         /* the stack shares its LDS with the hit buffers */
-            nr[lane] = ordered_runs_pf(k, a.pf, a.pf_lmin, valid, pi.x, pi.y, pi.z, hq, Lq, lds_inv64, lds_perm, stk + lane,
-                                       wruns + lane, a.flags);
+            nr[lane] = min(ordered_runs_pf(k, a.pf, a.pf_lmin, valid, pi.x, pi.y, pi.z, hq, Lq, lds_inv64, lds_perm, stk + lane,
+                                           wruns + lane, a.flags), TC_XRUNCAP);
         }
         /* the runs were written one lane per particle and are read by the particle's quad */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2186,7 +2195,7 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact_w(tc_xwvt_args a)
         const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
         /* lane 0 alone walks the cells: its runs land at wruns[64 s] */
         int nruns = ordered_runs_pf(k, a.pf, a.pf_lmin, lane == 0, xi, yi, zi, hq, Lq, lds_inv64, lds_perm, stk, wruns, a.flags);
-        nruns = U(nruns);
+        nruns = min(U(nruns), TC_XRUNCAP);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2825,8 +2834,10 @@ __global__ __launch_bounds__(TBN) void k_xruns(tc_dev_const k, const tc_prec *__
         const uint32_t pfl = (P.pack >> 4) & 0x7fu;
         const bool use = valid && (pfl & TC_PREC_VALID) && (pfl & TC_PREC_WARM);
         const int Lq = (int)(P.pack & 15u);
+        /* (writing straight into the particles' own lists -- 8-byte stores at a stride of TC_XRCAP entries per lane -- was
+         * slower than the coalesced copy below: 1.61 vs 1.46 ms) */
         int nr = ordered_runs_pf(k, pf, pf_lmin, use, pi.x, pi.y, pi.z, P.R, Lq > 0 ? Lq : 1, lds_inv64, lds_perm, stk,
-                                 wruns + lane, flags);
+                                 wruns + lane, nullptr);
         if (valid) xrn[i] = (use && nr <= TC_XRCAP) ? (uint32_t)nr : TC_XNONE;
         /* the runs were written one lane per particle ([slot][lane]); each particle's list is now copied out by the
          * whole wave, coalesced */
