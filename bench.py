@@ -225,7 +225,8 @@ def main():
     # every rank's view of the step, for the driver's 1 -> 8 curve (rank 0 prints them)
     mine = {"rank": rank, "phase_ms_per_step": {k: 1e3 * v[0] / args.steps for k, v in phases.items() if v[1]},
             "recv_bytes_per_step": recv_bytes, "local_set": lset["nloc"], "own": lset["nown"],
-            "local_set_over_own": lset["nloc"] / max(1, lset["nown"]), "passes_repeated": lset["retries"]}
+            "local_set_over_own": lset["nloc"] / max(1, lset["nown"]), "passes_repeated": lset["retries"],
+            "device_memory_used_gb": (lambda fr_tot: (fr_tot[1] - fr_tot[0]) / 1e9)(torch.cuda.mem_get_info())}
     per_rank = [mine]
     if use_dist:
         per_rank = [None] * world
