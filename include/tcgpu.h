@@ -168,6 +168,16 @@ int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
  *   "stats" [0]       keep per-particle work counters for tcgpu_last_density_stats
  *   "timing" [0]      record HIP events per phase for tcgpu_phase_times
  *   "fuse" [1]        fused density + sweep kernel; 0 = one plain kernel per reference loop
+ *   "sweep" [0]       the WVT displacement (wvt_relax.c:126-171): 0 = the reference's summation order and roundings -- f32
+ *                     accumulator, one rounding per neighbour, neighbours in ascending index -- bit for bit (the fused
+ *                     kernel lists each particle's neighbours in that order while it solves the densities, a second
+ *                     kernel evaluates the lists); 2 = the same sums by a stand-alone kernel (also taken automatically
+ *                     when the per-particle lists would not fit the device); 1 = f64 sums over 64 lanes rounded once
+ *                     (~1e-6 |delta| off per iteration; fused into the density kernel, the fastest)
+ *   "xsweep_kernel" [0] tests: 1 = sweep = 0/2 through the one-lane-per-particle kernel on the (x, y, z) cell table (an
+ *                     independent implementation of the same sums)
+ *   "xsweep_shift" [0] tuning: added to the cell level of the stand-alone exact sweep
+ *   "debug_fail_rank" [0] tests: rank (value - 1) reports a failure of its own before the ghost exchange
  *   "rows" [1]        row-run candidate streaming over the row-major mirror (set before upload)
  *   "level_shift" [1] cell level finer than the smoothing length by this many octree levels
  *   "level_scale" [2^(1/4)] the radius is multiplied by this before its level is chosen
