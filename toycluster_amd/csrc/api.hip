@@ -1130,7 +1130,9 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
         /* the sweep rides along only in round 2's mode (f64 sums, one rounding); the default sweep reproduces the
          * reference's order and roundings in a kernel of its own (k_wvt_exact), after the step is known */
         int ride = !with_wvt ? 0 : c->sweep_mode == 1 ? 1 : (c->sweep_mode == 0 && !c->xsweep_kernel) ? 2 : 0;
-        if (ride == 2 && !xlists_fit(c)) ride = 0;          /* too many particles for per-particle lists: the stand-alone sweep */
+        /* per-particle lists: not when they would not fit, and not for the few full-set passes of a sharded context (cold
+         * start, repeated pass) -- sized for everything they would be R times what the rank needs afterwards */
+        if (ride == 2 && ((multi(c) && c->local_full) || !xlists_fit(c))) ride = 0;
         if (ride == 2) {                                                            /* the ordered runs come from pf; */
             if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;              /* nobody needs the mirror */
         } else if ((rc = tc_launch_mirror(c))) return rc;
