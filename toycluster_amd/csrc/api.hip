@@ -649,6 +649,27 @@ extern "C" int tcgpu_debug_comm_selftest(tcgpu_ctx *c)
     bad |= hipStreamSynchronize(c->stream) != hipSuccess;
     bad |= hipMemcpy(h, d, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess;
     for (int i = 0; i < n && !bad; i++) bad = h[n + i] != 0x9e3779b9u * (uint32_t)(i + 1) || h[i] != h[n + i];
+    /* the shapes the ghost exchange produces: a group in which a peer sends nothing (its sends and receives are simply
+     * not posted: an EMPTY group must come back), and two messages of different, odd sizes per peer in one group (the
+     * index and the position part of an uneven tail shard) */
+    bad |= g_rccl.GroupStart() != ncclSuccess;
+    bad |= g_rccl.GroupEnd() != ncclSuccess;
+    const size_t n1 = 1237, n2 = 3 * 1237 + 5;                      /* bytes: neither a multiple of 4 nor of each other */
+    bad |= hipMemsetAsync(d + n, 0, n * sizeof(uint32_t), c->stream) != hipSuccess;
+    bad |= g_rccl.GroupStart() != ncclSuccess;
+    bad |= g_rccl.Send(d, n1, ncclInt8, c->rank, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+    bad |= g_rccl.Send((const char *)d + 2048, n2, ncclInt8, c->rank, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+    bad |= g_rccl.Recv(d + n, n1, ncclInt8, c->rank, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+    bad |= g_rccl.Recv((char *)(d + n) + 2048, n2, ncclInt8, c->rank, (ncclComm_t)c->comm, c->stream) != ncclSuccess;
+    bad |= g_rccl.GroupEnd() != ncclSuccess;
+    bad |= hipStreamSynchronize(c->stream) != hipSuccess;
+    bad |= hipMemcpy(h, d, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess;
+    {
+        const unsigned char *a = (const unsigned char *)h, *b = (const unsigned char *)(h + n);
+        for (size_t i = 0; i < n1 && !bad; i++) bad = a[i] != b[i];
+        for (size_t i = 0; i < n2 && !bad; i++) bad = a[2048 + i] != b[2048 + i];
+        for (size_t i = n1; i < 2048 && !bad; i++) bad = b[i] != 0;     /* nothing beyond the message lengths */
+    }
     free(h);
     hipFree(d);
     if (bad) TC_FAIL(c, TCGPU_ERR_COMM, "RCCL self-test failed");
