@@ -2600,12 +2600,20 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
                     use = hwv && !self;
                     mw = tc_ballot(use);
                 }
+                if (ord) {
+                    /* the staged hits are in ascending index: this step's sweep neighbours go straight to the next places of
+                     * the particle's list (streamed out: not to displace the positions in L2) */
+                    const int at = cwout + mask_rank(mw);
+                    if (use && at < TC_XLCAP) __builtin_nontemporal_store(jj, &a.xlist[(size_t)i * TC_XLCAP + at]);
+                    cwout = U(cwout + (int)__popcll(mw));
+                } else {
                 if (use) {
                     int sl2 = (whead + wcnt + mask_rank(mw)) & (TC_STAGE - 1);
                     wj[sl2] = jj;
                 }
                 wcnt = U(wcnt + (int)__popcll(mw));
                 if (wcnt >= 64) { convert_w(ftag, 64); wcnt = U(wcnt - 64); }
+                }
             }
             const float x = pj.x, y = pj.y, z = pj.z;
             const bool b_hb = r2 < hbsq, b_h0 = r2 < h0sq;
