@@ -1154,6 +1154,9 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
         /* per-particle lists: not when they would not fit, and not for the few full-set passes of a sharded context (cold
          * start, repeated pass) -- sized for everything they would be R times what the rank needs afterwards */
         if (ride == 2 && ((multi(c) && c->local_full) || !xlists_fit(c))) ride = 0;
+        /* nor on a cold pass: without a carried hsml no particle gets a list, and the wave-per-particle kernel that serves
+         * the unlisted few would serve everybody (41 ms at 2e6 against 8 ms for the stand-alone sweep) */
+        if (ride == 2 && need_guess) ride = 0;
         if (ride == 2) {                                                            /* the ordered runs come from pf; */
             if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;              /* nobody needs the mirror */
         } else if ((rc = tc_launch_mirror(c))) return rc;
@@ -1471,7 +1474,7 @@ extern "C" int tcgpu_bfld_from_rotA_sph(tcgpu_ctx *c, const float *apot, float *
  * [2] with a neighbour list, [3] mean runs, [4] mean listed neighbours, [5] max runs, [6] max listed */
 extern "C" int tcgpu_debug_xlist_stats(tcgpu_ctx *c, double *out)
 {
-    if (!c || !out || !c->xrn || !c->xlcnt) return TCGPU_ERR_ARG;
+    if (!c || !out || !c->xrn || !c->xlcnt || !c->xlist_valid) return TCGPU_ERR_ARG;     /* no lists from the last pass */
     TC_HIP(c, hipSetDevice(c->device));
     TC_HIP(c, hipStreamSynchronize(c->stream));
     const size_t n = (size_t)c->nloc;

@@ -44,6 +44,7 @@
 #define TC_NSTAGE 10
 struct tc_prof { uint64_t last; uint32_t acc[TC_NSTAGE]; };
 #define TC_PROF_PARAM , tc_prof *prof__ = nullptr
+#define TC_PROF_PARAM_DEF , tc_prof *prof__
 #define TC_PROF_PASS , prof__
 #define TC_STAGE_SWITCH(from, to)                                                          \
     do {                                                                                   \
@@ -55,6 +56,7 @@ struct tc_prof { uint64_t last; uint32_t acc[TC_NSTAGE]; };
     } while (0)
 #else
 #define TC_PROF_PARAM
+#define TC_PROF_PARAM_DEF
 #define TC_PROF_PASS
 #define TC_STAGE_SWITCH(from, to) do { } while (0)
 #endif
@@ -600,7 +602,7 @@ __device__ __forceinline__ uint32_t stream_rows(const tc_dev_const &k, float xi,
 
 template <bool XYZ_ONLY, class Body>
 __device__ __forceinline__ uint32_t stream_rows_q(const tc_dev_const &k, const tc_query &q, float xi, float yi, float zi,
-                                                  uint32_t *heads, Body &&body TC_PROF_PARAM)
+                                                  uint32_t *heads, Body &&body TC_PROF_PARAM_DEF)
 {
     const int lane = lane_id();
     TC_STAGE_SWITCH(ST_PROLOGUE, ST_PRODUCER);
@@ -2488,6 +2490,11 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
     uint32_t *dj = idx + TC_ITER_IDXCAP;
     float *dr2 = reinterpret_cast<float *>(dj + TC_STAGE);
     uint32_t *wj = reinterpret_cast<uint32_t *>(dr2 + TC_STAGE);
+    /* without round 2's sweep (WVT != 1) there is no second ring, and the area holds (j, x, y, z) per staged hit: the
+     * conversion then needs no second read of the positions -- a dependent gather whose latency four waves per SIMD
+     * did not cover (stage timers: convert_d 21 % of the waves' lives); r2 is recomputed there by the same function */
+    constexpr bool spos = WVT != 1;
+    float4 *dq = reinterpret_cast<float4 *>(dj);
     /* the plain fallback code stages positions: it reuses the whole ring area (4 x TC_STAGE floats) */
     tc_stage st;
     st.x = reinterpret_cast<float *>(dj);
@@ -2582,11 +2589,21 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             TC_STAGE_SWITCH(ST_TEST, ST_CONVERT_D);
             wave_lds_fence();
             int sl = (dhead + lane) & (TC_STAGE - 1);
-            const uint32_t jj = dj[sl];
-            const float r2 = dr2[sl];
-            /* the gather of the 64 positions is issued first; the sweep's part of the work -- which only needs the
-             * staged index and r2, and every other time runs a whole batch of pair terms -- goes on underneath it */
-            const float4 pj = PARK ? ld3(vmirror, jj) : k.pos4[jj];     /* 12 bytes: no register of the gather is free for reuse */
+            uint32_t jj;
+            float r2;
+            float4 pj;
+            if (spos) {
+                const float4 e = dq[sl];
+                jj = __float_as_uint(e.x);
+                pj = make_float4(e.y, e.z, e.w, 0.0f);
+                r2 = ngb_r2_w(xi, yi, zi, pj.x, pj.y, pj.z, k.boxhalf_f, k.boxsize_f, wr);      /* as in gather(): same bits */
+            } else {
+                jj = dj[sl];
+                r2 = dr2[sl];
+                /* the gather of the 64 positions is issued first; the sweep's part of the work -- which only needs the
+                 * staged index and r2, and every other time runs a whole batch of pair terms -- goes on underneath it */
+                pj = PARK ? ld3(vmirror, jj) : k.pos4[jj];     /* 12 bytes: no register of the gather is free for reuse */
+            }
             dhead = U((dhead + 64) & (TC_STAGE - 1));
             if (do_wvt) {
                 const bool hwv = r2 < hwsq;
@@ -2639,8 +2656,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
         auto pad_stage = [&](uint32_t padj, int nvalid) {
             if (lane >= nvalid) {
                 int sl = (dhead + lane) & (TC_STAGE - 1);
-                dj[sl] = padj;
-                dr2[sl] = HUGE_VALF;
+                if (spos) dq[sl] = make_float4(__uint_as_float(padj), HUGE_VALF, 0.0f, 0.0f);      /* r2 = infinity */
+                else { dj[sl] = padj; dr2[sl] = HUGE_VALF; }
             }
         };
         auto gather = [&](auto ftag, uint32_t j, float4 p, bool act) -> bool {
@@ -2652,7 +2669,8 @@ __device__ __forceinline__ void iter_one(const tc_iter_args &a, int i, unsigned 
             if (TC_ABLATE(k) == 2) { cs += (int)__popcll(md); return false; }      /* profiling only */
             if (hd) {
                 int sl = (dhead + dcnt + mask_rank(md)) & (TC_STAGE - 1);
-                dj[sl] = (uint32_t)j; dr2[sl] = r2;
+                if (spos) dq[sl] = make_float4(__uint_as_float((uint32_t)j), p.x, p.y, p.z);
+                else { dj[sl] = (uint32_t)j; dr2[sl] = r2; }
             }
             dcnt = U(dcnt + (int)__popcll(md));
             if (dcnt >= 64) {
