@@ -180,7 +180,8 @@ int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
  *   "debug_fail_rank" [0] tests: rank (value - 1) reports a failure of its own before the ghost exchange
  *   "rows" [1]        row-run candidate streaming over the row-major mirror (set before upload)
  *   "level_shift" [1] cell level finer than the smoothing length by this many octree levels
- *   "level_scale" [2^(1/4)] the radius is multiplied by this before its level is chosen
+ *   "level_scale" [auto] the radius is multiplied by this before its level is chosen (speed only; auto: 1.5 with the default
+ *                     sweep, whose ordered cell walk likes coarser leaves, 2^(1/4) with "sweep" = 1 / 2)
  *   "lmax" [auto]     deepest cell-table level (set before upload)
  *   "force_comm" [0]  tests: run the RCCL calls with a 1-rank communicator
  *   "curl_literal" [0] tests: the curl's literal pair-by-pair path (the NGBMAX-overflow fall-back) for every particle

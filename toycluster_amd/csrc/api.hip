@@ -144,7 +144,7 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     c->rows = 1;
     c->ghost_mode = 1;
     c->level_shift = 1;                          /* cells of h/4..h/2: fewest candidates per query (tools/fuse_stats.py) */
-    c->level_scale = 1.189207115002721;           /* 2^(1/4): cells of h/3.4..h/1.7, measured best (tools/shift_probe.py) */
+    c->level_scale = 0;                          /* automatic: tc_level_scale() */
     ok = ok && hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess;
     ok = ok && hipMemset(c->flags, 0, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMemset(c->norph, 0, sizeof(int)) == hipSuccess;
@@ -1505,7 +1505,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     if (!strcmp(name, "stats")) c->want_stats = value != 0;
     else if (!strcmp(name, "timing")) c->timing = value != 0;
     else if (!strcmp(name, "level_shift")) c->level_shift = (int)value;
-    else if (!strcmp(name, "level_scale")) c->level_scale = value > 0 ? value : 1.0;
+    else if (!strcmp(name, "level_scale")) c->level_scale = value > 0 ? value : 0.0;     /* 0: automatic */
     else if (!strcmp(name, "ablate")) c->ablate = (int)value;
     else if (!strcmp(name, "blocks_per_cu")) c->blocks_per_cu = (int)value;   /* profiling: cap the persistent grid */
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;

@@ -1147,7 +1147,7 @@ void tc_fill_const(const tcgpu_ctx *c, tc_dev_const *k)
     k->boxhalf_f = (float)(c->par.boxsize * 0.5);       /* src/tree.c:28 */
     k->lmax = c->lmax;
     k->level_shift = c->level_shift;
-    k->level_scale = c->level_scale;
+    k->level_scale = tc_level_scale(c);
     k->cells = c->cells;
     k->lvl = c->d_lvl;
     k->orphans = c->orphans;

@@ -340,7 +340,7 @@ int tc_launch_mark_interest(tcgpu_ctx *c)
         int64_t chunk = ((hi - lo + nblocks - 1) / nblocks + TB - 1) / TB * TB;
         nblocks = (hi - lo + chunk - 1) / chunk;
         k_mark_interest<<<(unsigned)nblocks, TB, 0, c->stream>>>(
-            c->g_pos4[c->gcur], c->g_hsml[c->gcur], (int)lo, (int)hi, (int)chunk, c->par.boxsize, mant, e2 - 1, c->level_scale,
+            c->g_pos4[c->gcur], c->g_hsml[c->gcur], (int)lo, (int)hi, (int)chunk, c->par.boxsize, mant, e2 - 1, tc_level_scale(c),
             c->level_shift, c->lmax, c->lp_max, c->margin_widen, c->mark_ignore_w, c->imask, c->isum, c->lvl_range,
             c->d_bbox);
     }

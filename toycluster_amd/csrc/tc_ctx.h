@@ -243,7 +243,7 @@ struct tcgpu_ctx {
     int mirror_valid;
     int rows;                     /* option: use the row-run fast path (default 1) */
     int level_shift;
-    double level_scale;
+    double level_scale;           /* option; 0 = automatic (tc_level_scale) */
     int lmax_override;
     int ablate;
     int curl_literal;             /* option (tests): the curl's literal per-pair path for every particle */
@@ -279,7 +279,17 @@ struct tcgpu_ctx {
     int timing;
 };
 
-#define TC_HIP(ctx, call)                                                                       \
+/* Cell size of a query relative to its radius (speed only, never results).  On the mirror's row-run path cells of
+ * h/3.4..h/1.7 (2^(1/4)) were measured best (tools/shift_probe.py); the default sweep's ordered cell walk (k_xruns) pays
+ * per cell, not per row, and likes them coarser: 1.5 gives 13.65 against 13.88 ms per iteration at 2e6, flat up to 1.7
+ * (tools/shift_probe_ord.py).  One value per context: records, interest marking and table ranges all use it. */
+static inline double tc_level_scale(const tcgpu_ctx *c)
+{
+    if (c->level_scale > 0) return c->level_scale;
+    return (c->sweep_mode == 0 && !c->xsweep_kernel) ? 1.5 : 1.189207115002721;
+}
+
+#define TC_HIP(ctx, call)                                                                      \
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \
         if (e_ != hipSuccess) {                                                                 \
