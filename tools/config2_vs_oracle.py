@@ -20,7 +20,6 @@ g.set_model(m); g.upload(pos, ids)
 t0 = time.perf_counter()
 lg = g.Regularise_sph_particles(max_iter=max_iter); g.Find_sph_quantities(); pg = g.particles()
 tg = time.perf_counter() - t0
-g.close()
 print("GPU: %d iterations, %.2f s, errMean %.6f at stop" % (len(lg), tg, lg[-1]["err_mean"]), flush=True)
 O.set_deviation(O.DEV_EXACT_BALL)
 o = O.Oracle(m, pos, ids, nthreads=16)
@@ -57,5 +56,15 @@ if ids_equal:
     bad += npos > 0
 else:
     bad += 1
+# the curl of a smooth vector potential on the relaxed state (K11, src/sph.c:216-300)
+if ids_equal:
+    a = ((po["rho_model"].astype(np.float64) / po["rho_model"].max()) ** 0.5).astype(np.float32)
+    apot = np.stack([a, a, a], axis=1)
+    o.set_apot(apot); bo = o.bfld_from_rotA()
+    bg = g.Bfld_from_rotA_SPH(apot)                  # on the GPU's own relaxed state
+    db = np.abs(bg - bo).max() / np.abs(bo).max()
+    print("curl: max |dB| / max |B| = %.3g" % db)
+    bad += db > 1e-5
+g.close()
 print("RESULT:", "bit-equal positions and log" if not bad else "DIFFERENCES (%d)" % bad)
 sys.exit(1 if bad else 0)

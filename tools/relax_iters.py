@@ -26,5 +26,7 @@ for it in range(iters):
     print("it %2d err_mean %.4f  listed %.4f  device %.2f ms: density %.2f  sweep %.2f  query_records %.2f  rest %.2f" %
           (it, em, listed, s, ms.get("density", 0), ms.get("wvt_sweep", 0), ms.get("query_records", 0),
            s - ms.get("density", 0) - ms.get("wvt_sweep", 0) - ms.get("query_records", 0)), flush=True)
+    if it == 0:
+        print("      cold pass, every phase:", {k: round(v, 2) for k, v in ms.items()}, flush=True)
 print("device total %.1f ms over %d iterations" % (tot, iters))
 g.close()
