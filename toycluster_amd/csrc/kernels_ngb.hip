@@ -1419,8 +1419,7 @@ struct tc_xwvt_args {
     const uint32_t *wl;              /* ... which k_iter wrote down (local slots), *wl_cnt of them: the work items, 16 per wave so
                                       * that a handful of particles does not cost the latency of a 64-particle group */
     const int *wl_cnt;
-    const uint32_t *pf; /* cell starts in curve order (tc_launch_pfirst), levels pf_lmin..lmax, entries biased per level */
-    int pf_lmin;
+    tc_pf pf;           /* cell starts in curve order (tc_launch_pfirst, tc_pf_first) */
 };
 
 /* periodic distance (one dimension) from x to the cell [c s, (c + 1) s) of a ring of circumference box; 0 inside */
@@ -1696,7 +1695,7 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact(tc_xwvt_args a)
  * one node per lane.  At the end the key ranges become index runs: [pf[a], pf[b + 1]).  Returns the number of runs. */
 /* `runs`: entry s of this lane's list at runs[s * stride], at most `cap` entries (a longer list is cut and its true length
  * returned; with `flags` the overflow is also reported as an error). */
-__device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint32_t *pf, int pf_lmin, bool valid, float xi,
+__device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const tc_pf &pf, bool valid, float xi,
                                                float yi, float zi, float hq, int Lq, const uint64_t *inv64,
                                                const unsigned char *perm, uint32_t *stk, uint2 *runs, int *flags,
                                                const int stride = 64, const int cap = TC_XRUNCAP)
@@ -1800,14 +1799,12 @@ __device__ __forceinline__ int ordered_runs_pf(const tc_dev_const &k, const uint
     const int ntrue = nout;
     if (nout > cap) { if (flags) atomicOr(&flags[3], 1); nout = cap; }
     /* key ranges -> index runs */
-    uint32_t off = 0;
-    for (int L = pf_lmin; L < Lq; L++) off += (1u << (3 * L)) + 1u;
-    const uint32_t *pfL = pf + off;
-    const uint32_t bias = (uint32_t)(Lq - pf_lmin) * (uint32_t)(k.n + 1);
+    const uint32_t offL = tc_pf_offset(pf.lmin, Lq), offC = tc_pf_offset(pf.lmin, pf.lc);
     int m = 0;
     for (int t = 0; t < nout; t++) {
         const uint2 kr = runs[(size_t)t * stride];
-        const uint32_t f0 = pfL[kr.x] - bias, e0 = pfL[kr.y + 1u] - bias;
+        const uint32_t f0 = tc_pf_first(pf, Lq, offL, offC, kr.x, (uint32_t)k.n);
+        const uint32_t e0 = tc_pf_first(pf, Lq, offL, offC, kr.y + 1u, (uint32_t)k.n);
         if (e0 > f0) { runs[(size_t)m * stride] = make_uint2(f0, e0); m++; }
     }
     return ntrue > cap ? ntrue : m;
@@ -1891,7 +1888,7 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact4(tc_xwvt_args a)
             }
             const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
             wave_lds_fence();                                         /* the stack shares its LDS with the hit buffers */
-            nr[lane] = min(ordered_runs_pf(k, a.pf, a.pf_lmin, valid, pi.x, pi.y, pi.z, hq, Lq, lds_inv64, lds_perm, stk + lane,
+            nr[lane] = min(ordered_runs_pf(k, a.pf, valid, pi.x, pi.y, pi.z, hq, Lq, lds_inv64, lds_perm, stk + lane,
                                            wruns + lane, a.flags), TC_XRUNCAP);
         }
         /* the runs were written one lane per particle and are read by the particle's quad */
@@ -2196,7 +2193,7 @@ __global__ __launch_bounds__(TBN) void k_wvt_exact_w(tc_xwvt_args a)
         }
         const int Lq = tc_query_level(k.boxsize, k.box_mant, k.box_exp, k.level_scale, k.level_shift + a.xshift, lmin, lmaxp, hq);
         /* lane 0 alone walks the cells: its runs land at wruns[64 s] */
-        int nruns = ordered_runs_pf(k, a.pf, a.pf_lmin, lane == 0, xi, yi, zi, hq, Lq, lds_inv64, lds_perm, stk, wruns, a.flags);
+        int nruns = ordered_runs_pf(k, a.pf, lane == 0, xi, yi, zi, hq, Lq, lds_inv64, lds_perm, stk, wruns, a.flags);
         nruns = min(U(nruns), TC_XRUNCAP);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -2324,8 +2321,7 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
         c->xruns_bytes = want;
     }
     a.runs = (uint2 *)c->xruns;
-    a.pf = c->pf;
-    a.pf_lmin = c->pf_lmin;
+    a.pf.tab = c->pf; a.pf.lmin = c->pf_lmin; a.pf.lc = c->pf_lc;
     a.orphans_only = 0;
     tc_phase_begin(c, PH_WVT);
     if (lists) {                                  /* k_iter listed the neighbours in index order: evaluate the lists ... */
@@ -2828,8 +2824,8 @@ __global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
  * order (ordered_runs_pf, one lane per particle), transposed into the particle's own list xr[i * TC_XRCAP ...] so that
  * the wavefront that later solves the particle reads them with one coalesced load.  Radius and level are the query
  * record's (k_prec): the ball k_iter gathers, R = max(1.23 hsml, hsml_wvt box). */
-__global__ __launch_bounds__(TBN) void k_xruns(tc_dev_const k, const tc_prec *__restrict__ prec, const uint32_t *__restrict__ pf,
-                                               int pf_lmin, uint2 *__restrict__ scratch, uint2 *__restrict__ xr,
+__global__ __launch_bounds__(TBN) void k_xruns(tc_dev_const k, const tc_prec *__restrict__ prec, const tc_pf pf,
+                                               uint2 *__restrict__ scratch, uint2 *__restrict__ xr,
                                                uint32_t *__restrict__ xrn, int *__restrict__ flags)
 {
     __shared__ uint32_t lds_stk[WPB * (TC_MAX_LEVEL + 1) * 64];
@@ -2862,7 +2858,7 @@ __global__ __launch_bounds__(TBN) void k_xruns(tc_dev_const k, const tc_prec *__
         const int Lq = (int)(P.pack & 15u);
         /* (writing straight into the particles' own lists -- 8-byte stores at a stride of TC_XRCAP entries per lane -- was
          * slower than the coalesced copy below: 1.61 vs 1.46 ms) */
-        int nr = ordered_runs_pf(k, pf, pf_lmin, use, pi.x, pi.y, pi.z, P.R, Lq > 0 ? Lq : 1, lds_inv64, lds_perm, stk,
+        int nr = ordered_runs_pf(k, pf, use, pi.x, pi.y, pi.z, P.R, Lq > 0 ? Lq : 1, lds_inv64, lds_perm, stk,
                                  wruns + lane, nullptr);
         if (valid) xrn[i] = (use && nr <= TC_XRCAP) ? (uint32_t)nr : TC_XNONE;
         /* the runs were written one lane per particle ([slot][lane]); each particle's list is now copied out by the
@@ -2929,7 +2925,7 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
             c->xruns_bytes = want;
         }
         TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
-        k_xruns<<<gx, TBN, 0, c->stream>>>(a.d.k, a.prec, c->pf, c->pf_lmin, (uint2 *)c->xruns, (uint2 *)c->xr, c->xrn, c->flags);
+        k_xruns<<<gx, TBN, 0, c->stream>>>(a.d.k, a.prec, tc_pf{c->pf, c->pf_lmin, c->pf_lc}, (uint2 *)c->xruns, (uint2 *)c->xr, c->xrn, c->flags);
         a.xr = (const uint2 *)c->xr; a.xrn = c->xrn; a.xlist = c->xlist; a.xlcnt = c->xlcnt;
         a.xun = c->xun; a.xun_cnt = (int *)(c->xun + c->xr_cap);
         TC_HIP(c, hipMemsetAsync(a.xun_cnt, 0, sizeof(int), c->stream));

@@ -920,11 +920,17 @@ int tc_launch_cells(tcgpu_ctx *c)
 
  * pf[L][p] = index of the first particle whose Peano key has a level-L prefix >= p, p = 0 .. 8^L (pf[L][8^L] = n): the
  * cells of a level taken in curve order are consecutive index ranges, so the particles of the cells p .. q are
- * [pf[L][p], pf[L][q + 1]) -- what the ordered traversal of the exact WVT sweep (k_wvt_exact4) turns its key ranges
- * into.  Built from the sorted keys: heads of runs are marked, empty cells take the head of the next occupied one
- * (one reverse running minimum over the whole table; level t's entries carry the bias t (n + 1) so that the minimum
- * never crosses from one level into the previous one).  Keys, not positions, decide membership: a particle with a
- * coordinate == boxsize ("orphan", k_cells) sits in the cell its key names and is found there. */
+ * [pf[L][p], pf[L][q + 1]) -- what the ordered traversals (k_xruns, k_wvt_exact4, k_wvt_exact_w) turn their key ranges
+ * into.  Keys, not positions, decide membership: a particle with a coordinate == boxsize ("orphan", k_cells) sits in
+ * the cell its key names and is found there.
+ * Levels lmin .. lc (lc = lmax - 3) are dense tables built from the sorted keys by one pass: heads of runs are marked,
+ * empty cells take the head of the next occupied one (one reverse running minimum over all of them; level t's entries
+ * carry the bias t (n + 1) so that the minimum never crosses from one level into the previous one).
+ * The three deepest levels hold 8/7 x 8^lmax entries -- 153 M at lmax = 9, where a sharded rank's local set (3.8e6
+ * particles of 1.6e7) occupies a small part of the key space but paid the memset and the scan of all of it (0.5 ms per
+ * iteration).  They are filled block by block instead (k_pf_deep): one wavefront per level-lc cell; an EMPTY cell is left
+ * alone (tc_pf_first answers from the level-lc entries, which say so), an occupied one gets its 8 + 64 + 512 entries
+ * from its own particles, the running minimum starting from the head of the next cell (= the cell's own end). */
 __global__ __launch_bounds__(TB) void k_pf_mark(const tc_u128 *__restrict__ key, int n, int lmin, int lmax, uint32_t *__restrict__ pf)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
@@ -949,6 +955,67 @@ __global__ __launch_bounds__(TB) void k_pf_mark(const tc_u128 *__restrict__ key,
     }
 }
 
+/* the levels lc + 1 .. lmax (at most three) under one level-lc cell per wavefront */
+__global__ __launch_bounds__(256) void k_pf_deep(const tc_u128 *__restrict__ key, int n, int lmin, int lc, int lmax,
+                                                 uint32_t *__restrict__ pf)
+{
+    __shared__ uint32_t lds[4][8 + 64 + 512];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t ncell = 1u << (3 * lc);
+    if (c >= ncell) return;
+    uint32_t offC = 0;
+    for (int L = lmin; L < lc; L++) offC += (1u << (3 * L)) + 1u;
+    const uint32_t biasC = (uint32_t)(lc - lmin) * (uint32_t)(n + 1);
+    const uint32_t lo = pf[offC + c] - biasC, hi = pf[offC + c + 1u] - biasC;
+    if (lo == hi) return;                                     /* empty: nobody reads below it (tc_pf_first) */
+    uint32_t *t = lds[wave];
+    const int nd = lmax - lc;                                 /* 1 .. 3 deep levels */
+    const int tot = nd == 3 ? 584 : nd == 2 ? 72 : 8;
+    for (int q = lane; q < tot; q += 64) t[q] = 0xffffffffu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    /* heads: the first particle of every deep cell (the keys are sorted: a particle is a head when its prefix differs
+     * from its predecessor's) */
+    for (uint32_t i = lo + (uint32_t)lane; i < hi; i += 64u) {
+        const tc_u128 k = key[i];
+        const tc_u128 kp = i > lo ? key[i - 1] : 0;
+        int base = 0;
+        for (int d = 1; d <= nd; d++) {
+            const int L = lc + d;
+            const uint32_t m = (1u << (3 * d)) - 1u;
+            const uint32_t p = (uint32_t)(k >> (128 - 3 * L)) & m, pp = (uint32_t)(kp >> (128 - 3 * L)) & m;
+            if (i == lo || p != pp) t[base + (int)p] = i;
+            base += 1 << (3 * d);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    /* running minimum from the back, starting at the head of whatever follows this cell (hi), level by level; a lane
+     * takes a contiguous piece, the pieces are chained through a wave scan */
+    uint32_t offL = offC + ncell + 1u;                        /* level lc + 1 starts behind level lc */
+    int base = 0;
+    for (int d = 1; d <= nd; d++) {
+        const int E = 1 << (3 * d);
+        const int per = (E + 63) / 64;                        /* 1, 1, 8 entries per lane */
+        const int a0 = lane * per, a1 = a0 + per < E ? a0 + per : E;
+        uint32_t mine = 0xffffffffu;
+        for (int q = a0; q < a1 && q < E; q++) mine = min(mine, t[base + q]);
+        /* suffix minimum over the lanes behind this one */
+        uint32_t suf = mine;
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_down((int)suf, sft);
+            if (lane + sft < 64) suf = min(suf, o);
+        }
+        uint32_t run = (uint32_t)__shfl_down((int)suf, 1);   /* minimum of everything behind this lane's piece */
+        if (lane == 63) run = 0xffffffffu;
+        run = min(run, hi);
+        for (int q = a1 - 1; q >= a0; q--) {
+            if (q < E) { run = min(run, t[base + q]); pf[offL + c * (uint32_t)E + (uint32_t)q] = run; }
+        }
+        offL += (1u << (3 * (lc + d))) + 1u;
+        base += E;
+    }
+}
+
 size_t tc_pf_entries(int lmin, int lmax)
 {
     size_t t = 0;
@@ -969,9 +1036,16 @@ int tc_launch_pfirst(tcgpu_ctx *c)
 {
     const int n = (int)c->nloc;
     const int lmin = c->lmin_tab, lmax = c->lmax;
+    /* dense by one scan up to level lc, block by block below it -- when the local set is thin in key space (a sharded
+     * rank: 3.8e6 particles under Lmax = 9 chosen for 1.6e7); a full set occupies nearly every block, and there the
+     * single scan over everything is the cheaper way (measured at 2e6: 0.22 against 0.30 ms, and 0.1 ms more in k_xruns
+     * for the look-ups' second load) */
+    const bool thin = (double)n < 0.06 * pow(8.0, (double)lmax);
+    const int lc = !thin ? lmax : lmax - 3 > lmin ? lmax - 3 : lmin;
     c->pf_valid = 0;
-    if ((uint64_t)(lmax - lmin + 1) * (uint64_t)(n + 1) >= 0xffffffffull) TC_FAIL(c, TCGPU_ERR_ARG, "cell-start table: too many particles for the level bias");
+    if ((uint64_t)(lc - lmin + 1) * (uint64_t)(n + 1) >= 0xffffffffull) TC_FAIL(c, TCGPU_ERR_ARG, "cell-start table: too many particles for the level bias");
     const size_t nent = tc_pf_entries(lmin, lmax);
+    const size_t nentC = tc_pf_entries(lmin, lc);
     if (nent > c->pf_alloc) {
         hipFree(c->pf); hipFree(c->pf_tmp);
         c->pf = nullptr; c->pf_tmp = nullptr; c->pf_alloc = 0;
@@ -981,15 +1055,20 @@ int tc_launch_pfirst(tcgpu_ctx *c)
         c->pf_alloc = nent;
     }
     tc_phase_begin(c, PH_CELLS);
-    TC_HIP(c, hipMemsetAsync(c->pf, 0xff, nent * sizeof(uint32_t), c->stream));
-    k_pf_mark<<<(n + 1 + TB - 1) / TB, TB, 0, c->stream>>>(c->key_sorted, n, lmin, lmax, c->pf);
-    auto it = std::make_reverse_iterator(c->pf + nent);
+    TC_HIP(c, hipMemsetAsync(c->pf, 0xff, nentC * sizeof(uint32_t), c->stream));
+    k_pf_mark<<<(n + 1 + TB - 1) / TB, TB, 0, c->stream>>>(c->key_sorted, n, lmin, lc, c->pf);
+    auto it = std::make_reverse_iterator(c->pf + nentC);
     size_t b = c->pf_tmp_bytes;
-    hipError_t e = rocprim::inclusive_scan(c->pf_tmp, b, it, it, nent, rocprim::minimum<uint32_t>(), c->stream);
+    hipError_t e = rocprim::inclusive_scan(c->pf_tmp, b, it, it, nentC, rocprim::minimum<uint32_t>(), c->stream);
+    if (e == hipSuccess && lmax > lc) {
+        const size_t ncell = (size_t)1 << (3 * lc);
+        k_pf_deep<<<(unsigned)((ncell + 3) / 4), 256, 0, c->stream>>>(c->key_sorted, n, lmin, lc, lmax, c->pf);
+    }
     tc_phase_end(c);
     TC_HIP(c, e);
     TC_HIP(c, hipGetLastError());
     c->pf_lmin = lmin;
+    c->pf_lc = lc;
     c->pf_valid = 1;
     return 0;
 }

@@ -219,7 +219,7 @@ struct tcgpu_ctx {
     uint32_t *pf;                 /* cell starts in curve order, levels pf_lmin..lmax (tc_launch_pfirst); entries carry a per-level bias */
     void *pf_tmp;
     size_t pf_alloc, pf_tmp_bytes;
-    int pf_lmin, pf_valid;        /* ... built for the current local order */
+    int pf_lmin, pf_lc, pf_valid; /* ... built for the current local order; levels <= pf_lc by one scan, deeper ones block by block */
     void *xr; uint32_t *xrn;      /* per-particle ordered run lists of the gather (k_xruns) and their lengths; on demand */
     uint32_t *xlist, *xlcnt;      /* per-particle sweep neighbours in index order, written by k_iter (WVT == 2) */
     uint32_t *xun;                /* particles k_iter could not list (+ their count at [xr_cap]) */
@@ -288,6 +288,33 @@ static inline double tc_level_scale(const tcgpu_ctx *c)
     if (c->level_scale > 0) return c->level_scale;
     return (c->sweep_mode == 0 && !c->xsweep_kernel) ? 1.5 : 1.189207115002721;
 }
+
+/* Cell starts in curve order (tc_launch_pfirst): first local index whose level-L key prefix is >= p.  Levels lmin..lc are
+ * dense tables made by one scan (entries carry the bias (L - lmin) (n + 1)); a deeper level is filled block by block --
+ * only the 8^(L - lc) entries under OCCUPIED level-lc cells exist, an empty cell answers from its own level-lc entry. */
+struct tc_pf {
+    const uint32_t *tab;
+    int lmin, lc;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t tc_pf_offset(int lmin, int L)
+{
+    uint32_t off = 0;
+    for (int t = lmin; t < L; t++) off += (1u << (3 * t)) + 1u;
+    return off;
+}
+/* offL = tc_pf_offset(lmin, L), offC = tc_pf_offset(lmin, lc): hoisted by the caller */
+__device__ __forceinline__ uint32_t tc_pf_first(const tc_pf &P, int L, uint32_t offL, uint32_t offC, uint32_t p, uint32_t n)
+{
+    if (L <= P.lc) return P.tab[offL + p] - (uint32_t)(L - P.lmin) * (n + 1u);
+    if (p >= (1u << (3 * L))) return n;
+    const uint32_t c = p >> (3 * (L - P.lc));
+    const uint32_t biasC = (uint32_t)(P.lc - P.lmin) * (n + 1u);
+    const uint32_t lo = P.tab[offC + c] - biasC, hi = P.tab[offC + c + 1u] - biasC;
+    if (lo == hi) return lo;                       /* nothing under this level-lc cell: the next occupied one starts at lo */
+    return P.tab[offL + p];
+}
+#endif
 
 #define TC_HIP(ctx, call)                                                                      \
     do {                                                                                        \
