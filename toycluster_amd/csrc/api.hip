@@ -132,7 +132,10 @@ extern "C" int tcgpu_create(tcgpu_ctx **out, int device)
     ok = ok && hipHostMalloc(&c->h_flags, sizeof(int) * 8) == hipSuccess;
     ok = ok && hipMalloc(&c->orphans, sizeof(uint32_t) * TC_MAX_ORPHANS) == hipSuccess;
     ok = ok && hipMalloc(&c->norph, sizeof(int)) == hipSuccess;
-    ok = ok && hipMalloc(&c->work_ctr, 8 * 16 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc(&c->work_ctr, 2 * 8 * 16 * sizeof(int)) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&c->ngb_cnt, sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->lvl_range, 8 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc(&c->d_lvl, sizeof(tc_level_desc) * (TC_MAX_LEVEL + 2)) == hipSuccess;
@@ -189,6 +192,9 @@ extern "C" void tcgpu_destroy(tcgpu_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->comm);
     for (int i = 0; i < c->caprecs; i++) { hipEventDestroy(c->recs[i].a); hipEventDestroy(c->recs[i].b); }
     free(c->recs);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
 }

@@ -2324,17 +2324,30 @@ int tc_launch_wvt_exact(tcgpu_ctx *c, double step)
     a.pf.tab = c->pf; a.pf.lmin = c->pf_lmin; a.pf.lc = c->pf_lc;
     a.orphans_only = 0;
     tc_phase_begin(c, PH_WVT);
-    if (lists) {                                  /* k_iter listed the neighbours in index order: evaluate the lists ... */
-        TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
+    if (lists) {
+        /* k_iter listed the neighbours in index order: k_wvt_chain4 evaluates the lists.  The few particles without a list
+         * (one wavefront each, a serial chain of up to 2 360 additions: 0.3 ms of latency, next to no throughput) go to a
+         * side stream FIRST and run underneath: the list kernel's persistent blocks take the slots they leave and the
+         * rest as they finish (dynamic work queue, no block waits for another).  They write disjoint particles. */
+        TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 2 * 8 * 16 * sizeof(int), c->stream));
+        TC_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+        TC_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        tc_xwvt_args a2 = a;
+        a2.k.work_ctr = c->work_ctr + 8 * 16;
+        k_wvt_exact_w<<<gw, TBN, 0, c->stream2>>>(a2);
+        TC_HIP(c, hipEventRecord(c->ev_join, c->stream2));
         k_wvt_chain4<<<xgrid(c, nloc, k_wvt_chain4), TBN, 0, c->stream>>>(a);
-    }                                             /* ... and k_wvt_exact4 below takes the particles that have none */
+        TC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        tc_phase_end(c);
+        TC_HIP(c, hipGetLastError());
+        return 0;
+    }
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));
     /* option "xsweep_kernel" = 1 (tests): the one-lane-per-particle kernel on the (x, y, z) cell table -- an independent
      * second implementation of the same sums.  (A third layout -- one lane per particle with candidates served from LDS
      * tiles of the index space -- was tried in round 3 and dropped: the Peano runs of a ball are short and scattered, a
      * group of 64 particles touches hundreds of 128-particle tiles: 26 ms.) */
     if (c->xsweep_kernel == 1) k_wvt_exact<<<g1, TBN, 0, c->stream>>>(a);
-    else if (lists) k_wvt_exact_w<<<gw, TBN, 0, c->stream>>>(a);      /* only the few particles without a list: a wavefront each */
     else k_wvt_exact4<<<g4, TBN, 0, c->stream>>>(a);
     tc_phase_end(c);
     TC_HIP(c, hipGetLastError());

@@ -231,7 +231,9 @@ struct tcgpu_ctx {
     int blocks_per_cu;            /* profiling only: cap on the co-resident blocks per CU of the persistent kernels (0 = all) */
     uint32_t *orphans;
     int *norph;
-    int *work_ctr;                /* 8 x 16 ints: per-XCD-group particle counters of the dynamic work queue */
+    int *work_ctr;                /* 8 x 16 ints: per-XCD-group particle counters of the dynamic work queue (+ a second set for the side stream) */
+    hipStream_t stream2;          /* side stream: the few unlisted particles of the sweep run under the list evaluation */
+    hipEvent_t ev_fork, ev_join;
     int index_valid;
     uint32_t *cum;                /* cells of levels lmin_rm..lmax_rm, +1 */
     float4 *mirror;               /* (lmax_rm - lmin_rm + 1) x cap slots, +1 pad */
