@@ -2453,8 +2453,15 @@ __global__ __launch_bounds__(256) void k_prec(tc_dev_const k0, const float *__re
  * Round 2 tried 5 waves per SIMD (one 640-entry region shared by the two lists growing towards each other = 32 KB per
  * block, 96 VGPRs): the occupancy sweep (tools/occupancy_sweep.py: 30.8 / 16.7 / 12.6 / 10.8 ms at 1 / 2 / 3 / 4 blocks
  * per CU) promised -10 %, the build lost 4 % (24 VGPRs spilled to scratch, more scalar spills) -- not taken. */
+#ifdef TC_TRY_W5               /* experiment (make w5): 8 KB of LDS per wave and 96 VGPRs for a fifth wave per SIMD */
+#define TC_ICAP 384
+#define TC_OCAP 256
+#define TC_ITER_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
+#else
 #define TC_ICAP 512            /* inner entries in LDS */
 #define TC_OCAP 384            /* outer entries in LDS */
+#define TC_ITER_ATTR
+#endif
 #define TC_ITER_IDXCAP 256
 #define TC_ITER_MINWAVES 4
 #define TC_LDS_PER_WAVE_ITER ((TC_ICAP + TC_OCAP) * sizeof(double) + TC_ITER_IDXCAP * sizeof(uint32_t) + 4 * TC_STAGE * sizeof(float))
@@ -2804,7 +2811,7 @@ extern "C" int tcgpu_debug_stage_cycles(uint32_t *out, int nwaves)
 #endif
 
 template <bool STATS, int WVT>
-__global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) void k_iter(tc_iter_args a)
+__global__ __launch_bounds__(TBN, TC_ITER_MINWAVES) TC_ITER_ATTR void k_iter(tc_iter_args a)
 {
     __shared__ __align__(16) unsigned char lds_raw[WPB * TC_LDS_PER_WAVE_ITER];
     const int wave = threadIdx.x >> 6;
