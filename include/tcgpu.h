@@ -182,6 +182,8 @@ int tcgpu_comm_init_loopback(tcgpu_ctx **ctxs, int nranks);
  *   "level_shift" [1] cell level finer than the smoothing length by this many octree levels
  *   "level_scale" [auto] the radius is multiplied by this before its level is chosen (speed only; auto: 1.5 with the default
  *                     sweep, whose ordered cell walk likes coarser leaves, 2^(1/4) with "sweep" = 1 / 2)
+ *   "pf_mode" [0]     tests: how the curve-ordered cell starts are built -- 0 automatic, 1 every level by one scan, 2 the three
+ *                     deepest levels block by block (what a sharded rank's thin local set gets); same table either way
  *   "lmax" [auto]     deepest cell-table level (set before upload)
  *   "force_comm" [0]  tests: run the RCCL calls with a 1-rank communicator
  *   "curl_literal" [0] tests: the curl's literal pair-by-pair path (the NGBMAX-overflow fall-back) for every particle

@@ -465,6 +465,28 @@ def test_wvt_sweep_second_implementation_and_f64_mode(golden_case):
             assert rel(hs, c["w_hsml"]).max() < 3e-7 and np.abs(de - c["w_delta"]).max() < 2e-6 * scale
 
 
+def test_cell_start_table_built_either_way_gives_the_same_runs():
+    """The curve-ordered cell starts (pf) are made by one scan over every level, or -- for the thin local set of a
+    sharded rank -- with the three deepest levels filled block by block under occupied cells only (k_pf_deep); the
+    ordered walks must read the same index runs from both: whole relaxations equal bit for bit, with either sweep
+    implementation that walks the table."""
+    n = 60013
+    m = M.preset("merger", n)
+    pos, ids = M.sample_gas(m, n, seed=77)
+    for sweep in (0, 2):                                   # the list path (k_xruns) and the stand-alone kernel (k_wvt_exact4)
+        out = []
+        for mode in (1, 2):
+            g = binding.TcGpu(0, options={"pf_mode": mode, "sweep": sweep})
+            g.set_model(m); g.upload(pos, ids)
+            log = g.Regularise_sph_particles(max_iter=5); g.Find_sph_quantities()
+            out.append((log, g.particles()))
+            g.close()
+        (la, pa), (lb, pb) = out
+        assert [(a["step"], a["err_mean"], a["err_max"]) for a in la] == [(b["step"], b["err_mean"], b["err_max"]) for b in lb]
+        for k in ("id", "pos", "hsml", "rho", "varhsmlfac"):
+            assert np.array_equal(pa[k], pb[k]), (sweep, k)
+
+
 def test_relaxation_short(gpu, golden_case):
     c = golden_case
     gpu.set_model(c["model"])

@@ -1516,6 +1516,7 @@ extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
     else if (!strcmp(name, "blocks_per_cu")) c->blocks_per_cu = (int)value;   /* profiling: cap the persistent grid */
     else if (!strcmp(name, "fuse")) c->fuse = value != 0;
     else if (!strcmp(name, "sweep")) c->sweep_mode = (int)value;         /* 0: the reference's order and roundings, lists from k_iter (default); 2: the same, stand-alone; 1: f64 sums, rounded once */
+    else if (!strcmp(name, "pf_mode")) { c->pf_mode = (int)value; c->pf_valid = 0; }
     else if (!strcmp(name, "xsweep_shift")) c->xsweep_shift = (int)value;
     else if (!strcmp(name, "xsweep_kernel")) c->xsweep_kernel = (int)value;
     else if (!strcmp(name, "curl_literal")) c->curl_literal = value != 0;

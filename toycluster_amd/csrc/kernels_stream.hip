@@ -1040,7 +1040,7 @@ int tc_launch_pfirst(tcgpu_ctx *c)
      * rank: 3.8e6 particles under Lmax = 9 chosen for 1.6e7); a full set occupies nearly every block, and there the
      * single scan over everything is the cheaper way (measured at 2e6: 0.22 against 0.30 ms, and 0.1 ms more in k_xruns
      * for the look-ups' second load) */
-    const bool thin = (double)n < 0.06 * pow(8.0, (double)lmax);
+    const bool thin = c->pf_mode == 1 ? false : c->pf_mode == 2 ? true : (double)n < 0.06 * pow(8.0, (double)lmax);   /* option "pf_mode": tests */
     const int lc = !thin ? lmax : lmax - 3 > lmin ? lmax - 3 : lmin;
     c->pf_valid = 0;
     if ((uint64_t)(lc - lmin + 1) * (uint64_t)(n + 1) >= 0xffffffffull) TC_FAIL(c, TCGPU_ERR_ARG, "cell-start table: too many particles for the level bias");

@@ -219,6 +219,7 @@ struct tcgpu_ctx {
     uint32_t *pf;                 /* cell starts in curve order, levels pf_lmin..lmax (tc_launch_pfirst); entries carry a per-level bias */
     void *pf_tmp;
     size_t pf_alloc, pf_tmp_bytes;
+    int pf_mode;                  /* option (tests): 0 automatic, 1 every level by the one scan, 2 the deep levels block by block */
     int pf_lmin, pf_lc, pf_valid; /* ... built for the current local order; levels <= pf_lc by one scan, deeper ones block by block */
     void *xr; uint32_t *xrn;      /* per-particle ordered run lists of the gather (k_xruns) and their lengths; on demand */
     uint32_t *xlist, *xlcnt;      /* per-particle sweep neighbours in index order, written by k_iter (WVT == 2) */
