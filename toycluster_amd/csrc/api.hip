@@ -821,30 +821,33 @@ static int agree_status(tcgpu_ctx *c, int rc_local, const char *what)
     return 0;
 }
 
-static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
+/* rc_in: a failure of this rank on the way here (the marking launch); it is reported through the agreed status */
+static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc, int rc_in)
 {
     const int R = c->nranks, me = c->rank;
     int rc;
     int64_t lo, hi;
     tc_own_range(c, &lo, &hi);
+    /* A failure only this rank sees (a launch, a copy) must not make it leave while the others wait in the next collective:
+     * it is remembered, the collectives below are still entered, and the status is agreed before anybody sends. */
+    int rc_early = rc_in;
     tc_phase_begin(c, PH_COMM);
     rc = allgather_chunks(c, c->pyr_all, c->pyr_chunk * sizeof(uint32_t));
     tc_phase_end(c);
-    if (rc) return rc;
+    if (rc && !rc_early) rc_early = rc;
     tc_phase_begin(c, PH_LOCAL);
     rc = tc_launch_ghost_count(c);
     tc_phase_end(c);
-    if (rc) return rc;
+    if (rc && !rc_early) rc_early = rc;
     tc_phase_begin(c, PH_COMM);
     rc = allgather_chunks(c, c->ghost_cnt_mat, (size_t)R * sizeof(int));
-    if (rc) { tc_phase_end(c); return rc; }
-    TC_HIP(c, hipMemcpyAsync(c->h_cnt_mat, c->ghost_cnt_mat, (size_t)R * R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     tc_phase_end(c);
-    /* everything from here to the exchange can fail on one rank alone: the status is agreed before anybody sends */
+    if (rc && !rc_early) rc_early = rc;
     int soff[TC_GHOST_MAXR + 1], roff[TC_GHOST_MAXR + 1];
     size_t nsend = 0, nrecv = 0;
     auto prepare = [&]() -> int {
         int r;
+        TC_HIP(c, hipMemcpyAsync(c->h_cnt_mat, c->ghost_cnt_mat, (size_t)R * R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         if ((r = tc_finish_local_layout(c))) return r;                /* synchronises: counts and table layout */
         soff[0] = roff[0] = 0;
         for (int q = 0; q < R; q++) {
@@ -886,7 +889,7 @@ static int exchange_ghosts(tcgpu_ctx *c, int64_t *nloc)
         tc_phase_end(c);
         return r;
     };
-    rc = prepare();
+    rc = rc_early ? rc_early : prepare();
     if (c->debug_fail_rank == me + 1 && !rc) {                        /* tests: a failure only this rank sees */
         snprintf(c->err, sizeof(c->err), "injected failure on rank %d", me);
         rc = TCGPU_ERR_NOMEM;
@@ -958,7 +961,7 @@ static int build_local(tcgpu_ctx *c, int full, int with_cells, int mark_dirty)
         tc_phase_begin(c, PH_LOCAL);
         rc = tc_launch_mark_interest(c);
         tc_phase_end(c);
-        if (!rc) rc = exchange_ghosts(c, &nloc);                      /* synchronises: the launch sizes below need nloc */
+        rc = exchange_ghosts(c, &nloc, rc);                          /* synchronises: the launch sizes below need nloc */
         if (rc) return rc;
         c->local_full = 0;
         c->nloc = nloc;
