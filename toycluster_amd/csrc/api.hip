@@ -1166,6 +1166,7 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
         /* nor on a cold pass: without a carried hsml no particle gets a list, and the wave-per-particle kernel that serves
          * the unlisted few would serve everybody (41 ms at 2e6 against 8 ms for the stand-alone sweep) */
         if (ride == 2 && need_guess) ride = 0;
+        if (ride == 2 && tc_ensure_xlists(c)) ride = 0;                             /* memory not to be had: no lists this pass */
         if (ride == 2) {                                                            /* the ordered runs come from pf; */
             if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;              /* nobody needs the mirror */
         } else if ((rc = tc_launch_mirror(c))) return rc;

@@ -2896,6 +2896,32 @@ __global__ __launch_bounds__(TBN) void k_xruns(tc_dev_const k, const tc_prec *__
     });
 }
 
+/* run lists and neighbour lists of every local slot (own particles use theirs), sized by the local set of this pass (with
+ * head room), not by the particle capacity: on a sharded rank the local set is a fraction of everything, and the lists are
+ * what takes the memory (xlists_fit, api.hip).  Returns non-zero when the memory is not to be had: the caller then runs
+ * the pass without lists (stand-alone sweep) -- a rank must not fail alone over a size only it knows. */
+int tc_ensure_xlists(tcgpu_ctx *c)
+{
+    if (c->xr_cap >= (size_t)c->nloc) return 0;
+    size_t cap = (size_t)c->nloc + (size_t)c->nloc / 8 + 1024;
+    if (cap > (size_t)c->cap) cap = (size_t)c->cap;
+    hipFree(c->xr); hipFree(c->xrn); hipFree(c->xlist); hipFree(c->xlcnt); hipFree(c->xun);
+    c->xr = nullptr; c->xrn = nullptr; c->xlist = nullptr; c->xlcnt = nullptr; c->xun = nullptr; c->xr_cap = 0;
+    bool ok = hipMalloc(&c->xr, cap * TC_XRCAP * sizeof(uint2)) == hipSuccess;
+    ok = ok && hipMalloc(&c->xrn, cap * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&c->xlist, cap * TC_XLCAP * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&c->xlcnt, cap * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc(&c->xun, (cap + 4) * sizeof(uint32_t)) == hipSuccess;           /* the count lives behind the list */
+    if (!ok) {
+        (void)hipGetLastError();                                                         /* not an error of the pass */
+        hipFree(c->xr); hipFree(c->xrn); hipFree(c->xlist); hipFree(c->xlcnt); hipFree(c->xun);
+        c->xr = nullptr; c->xrn = nullptr; c->xlist = nullptr; c->xlcnt = nullptr; c->xun = nullptr;
+        return -1;
+    }
+    c->xr_cap = cap;
+    return 0;
+}
+
 /* with_wvt: 0 density only; 1 + round 2's f64 sweep sums (ustep); 2 + the sweep's neighbours listed in index order
  * (xlist / xlcnt, for k_wvt_chain4) with the gather fed from ordered runs */
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
@@ -2924,18 +2950,7 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
         /* run lists and neighbour lists of every local slot (own particles use theirs) */
         /* sized by the local set of this pass (with head room), not by the particle capacity: on a sharded rank the local
          * set is a fraction of everything, and the lists are what takes the memory (xlists_fit, api.hip) */
-        size_t cap = (size_t)c->nloc + (size_t)c->nloc / 8 + 1024;
-        if (cap > (size_t)c->cap) cap = (size_t)c->cap;
-        if (c->xr_cap < (size_t)c->nloc) {
-            hipFree(c->xr); hipFree(c->xrn); hipFree(c->xlist); hipFree(c->xlcnt); hipFree(c->xun);
-            c->xr = nullptr; c->xrn = nullptr; c->xlist = nullptr; c->xlcnt = nullptr; c->xun = nullptr; c->xr_cap = 0;
-            TC_HIP(c, hipMalloc(&c->xr, cap * TC_XRCAP * sizeof(uint2)));
-            TC_HIP(c, hipMalloc(&c->xrn, cap * sizeof(uint32_t)));
-            TC_HIP(c, hipMalloc(&c->xlist, cap * TC_XLCAP * sizeof(uint32_t)));
-            TC_HIP(c, hipMalloc(&c->xlcnt, cap * sizeof(uint32_t)));
-            TC_HIP(c, hipMalloc(&c->xun, (cap + 4) * sizeof(uint32_t)));           /* the count lives behind the list */
-            c->xr_cap = cap;
-        }
+        if (tc_ensure_xlists(c)) TC_FAIL(c, TCGPU_ERR_NOMEM, "per-particle lists of the ordered gather: allocation failed");
         const int gx = xgrid(c, nloc, k_xruns);
         const size_t want = (size_t)gx * WPB * TC_XRUNCAP * 64 * sizeof(uint2);
         if (c->xruns_bytes < want) {

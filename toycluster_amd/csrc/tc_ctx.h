@@ -424,6 +424,7 @@ int tc_launch_scatter_bfld(tcgpu_ctx *c, const float *l_bfld);
 /* neighbour kernels */
 int tc_launch_density(tcgpu_ctx *c);
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt);   /* fused density (+ unit-step WVT sums) */
+int tc_ensure_xlists(tcgpu_ctx *c);               /* per-particle lists of the ordered gather for this pass's local set; != 0: no memory */
 int tc_launch_apply_step(tcgpu_ctx *c, double step);  /* delta (G order) = step * ustep (local order) */
 int tc_launch_wvt(tcgpu_ctx *c, double step);
 int tc_launch_wvt_exact(tcgpu_ctx *c, double step);   /* delta in the reference's summation order and roundings */
