@@ -70,3 +70,22 @@ def test_code_object_guard_accepts_the_libraries_and_refuses_a_tight_limit():
         assert "k_iter" in ok.stdout
         tight = subprocess.run([sys.executable, tool, lib, "--limit", "50000"], capture_output=True, text=True)
         assert tight.returncode == 1 and "FAIL" in tight.stderr
+
+
+def test_bench_contract_surface_and_profile_guard():
+    """bench.py keeps the driver's flags; the counter-derived figures it quotes from profiles/dominant_kernel.json are
+    refused when the kernel sources have changed since the profile was taken (tools/roofline_valu.py hashes them) --
+    the committed profile must belong to the committed sources."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
+    sys.path.insert(0, ROOT)
+    from tools import roofline_valu
+    pj = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel.json")))
+    assert pj["kernel"] == "k_iter" and pj["n_particles"] == 2_000_000
+    assert pj["kernel_sources_sha256"] == roofline_valu.kernel_sources_sha256(ROOT), \
+        "kernel sources changed since profiles/dominant_kernel.json was taken: rerun tools/profile_round2.sh + tools/roofline_valu.py"
