@@ -430,6 +430,7 @@ extern "C" int tcgpu_upload_particles(tcgpu_ctx *c, int64_t n, const float *pos,
     c->w_valid = 0;
     c->pos_all_valid = 1;                         /* every rank was given every position */
     c->nloc = 0; c->nown = 0; c->local_full = 0;
+    c->lists_unfit = 0;
     c->need_guess = 1;
     if (hsml) {                                   /* warm start: the guess is only read where hsml == 0 */
         c->need_guess = 0;
@@ -1162,11 +1163,12 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
         int ride = !with_wvt ? 0 : c->sweep_mode == 1 ? 1 : (c->sweep_mode == 0 && !c->xsweep_kernel) ? 2 : 0;
         /* per-particle lists: not when they would not fit, and not for the few full-set passes of a sharded context (cold
          * start, repeated pass) -- sized for everything they would be R times what the rank needs afterwards */
-        if (ride == 2 && ((multi(c) && c->local_full) || !xlists_fit(c))) ride = 0;
+        if (ride == 2 && multi(c) && c->local_full) ride = 0;
+        if (ride == 2) { c->lists_unfit = !xlists_fit(c); if (c->lists_unfit) ride = 0; }
         /* nor on a cold pass: without a carried hsml no particle gets a list, and the wave-per-particle kernel that serves
          * the unlisted few would serve everybody (41 ms at 2e6 against 8 ms for the stand-alone sweep) */
         if (ride == 2 && need_guess) ride = 0;
-        if (ride == 2 && tc_ensure_xlists(c)) ride = 0;                             /* memory not to be had: no lists this pass */
+        if (ride == 2 && tc_ensure_xlists(c)) { ride = 0; c->lists_unfit = 1; }       /* memory not to be had: no lists this pass */
         if (ride == 2) {                                                            /* the ordered runs come from pf; */
             if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;              /* nobody needs the mirror */
         } else if ((rc = tc_launch_mirror(c))) return rc;

@@ -219,6 +219,7 @@ struct tcgpu_ctx {
     uint32_t *pf;                 /* cell starts in curve order, levels pf_lmin..lmax (tc_launch_pfirst); entries carry a per-level bias */
     void *pf_tmp;
     size_t pf_alloc, pf_tmp_bytes;
+    int lists_unfit;              /* the per-particle lists of the ordered gather did not fit in the last pass that wanted them */
     int pf_mode;                  /* option (tests): 0 automatic, 1 every level by the one scan, 2 the deep levels block by block */
     int pf_lmin, pf_lc, pf_valid; /* ... built for the current local order; levels <= pf_lc by one scan, deeper ones block by block */
     void *xr; uint32_t *xrn;      /* per-particle ordered run lists of the gather (k_xruns) and their lengths; on demand */
@@ -285,11 +286,13 @@ struct tcgpu_ctx {
 /* Cell size of a query relative to its radius (speed only, never results).  On the mirror's row-run path cells of
  * h/3.4..h/1.7 (2^(1/4)) were measured best (tools/shift_probe.py); the default sweep's ordered cell walk (k_xruns) pays
  * per cell, not per row, and likes them coarser: 1.5 gives 13.65 against 13.88 ms per iteration at 2e6, flat up to 1.7
- * (tools/shift_probe_ord.py).  One value per context: records, interest marking and table ranges all use it. */
+ * (tools/shift_probe_ord.py).  One value per pass: records, interest marking and table ranges all use it.  When the
+ * per-particle lists of that walk do not fit (1e8 particles on one GPU) the passes run on the mirror and the stand-alone
+ * sweep, and the finer cells are the better ones again (measured at 1e8: 813 against 872 ms per iteration). */
 static inline double tc_level_scale(const tcgpu_ctx *c)
 {
     if (c->level_scale > 0) return c->level_scale;
-    return (c->sweep_mode == 0 && !c->xsweep_kernel) ? 1.5 : 1.189207115002721;
+    return (c->sweep_mode == 0 && !c->xsweep_kernel && !c->lists_unfit) ? 1.5 : 1.189207115002721;
 }
 
 /* Cell starts in curve order (tc_launch_pfirst): first local index whose level-L key prefix is >= p.  Levels lmin..lc are
