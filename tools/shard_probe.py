@@ -36,7 +36,22 @@ pos, ids = hostio.sample_gas(s, nthreads=8)
 m = hostio.setup_to_model(s)
 
 
+def device_bytes_used():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    fr, tot = C.c_size_t(), C.c_size_t()
+    hip.hipMemGetInfo(C.byref(fr), C.byref(tot))
+    return tot.value - fr.value
+
+
+BASE_USED = None
+
+
 def run_group(nranks):
+    global BASE_USED
+    if BASE_USED is None:
+        binding.TcGpu(0).close()             # runtime initialised: what is in use before any particle array exists
+        BASE_USED = device_bytes_used()
     ctxs = [binding.TcGpu(0) for _ in range(nranks)]
     if nranks > 1:
         binding.loopback_group(ctxs)
@@ -66,7 +81,11 @@ def run_group(nranks):
     th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
     [t.start() for t in th]
     [t.join() for t in th]
+    used = device_bytes_used()               # every context of the group still holds its allocations
     [c.close() for c in ctxs]
+    for o in out:
+        if isinstance(o, dict):
+            o["device_bytes_per_rank_mean"] = (used - BASE_USED) / nranks
     return out
 
 

@@ -296,9 +296,7 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
         TC_HIP(c, hipMalloc(&c->guess, 3 * cap * sizeof(float)));     /* also 3 floats/particle of scratch (presentation) */
         TC_HIP(c, hipMalloc(&c->hwvt, cap * sizeof(float)));
         TC_HIP(c, hipMalloc(&c->delta, 3 * cap * sizeof(float)));
-        TC_HIP(c, hipMalloc(&c->ustep, 3 * cap * sizeof(double)));
         TC_HIP(c, hipMalloc(&c->rhom_next, cap * sizeof(float)));
-        TC_HIP(c, hipMalloc(&c->stats, 4 * cap * sizeof(uint32_t)));
         TC_HIP(c, hipMalloc(&c->ngb_buf, cap * sizeof(int32_t)));
         TC_HIP(c, hipMemset(c->hwvt, 0, cap * sizeof(float)));
         TC_HIP(c, hipMemset(c->delta, 0, 3 * cap * sizeof(float)));
@@ -364,20 +362,7 @@ static int ensure_capacity(tcgpu_ctx *c, int64_t n)
             TC_HIP(c, hipMalloc(&c->scan_tmp, c->scan_tmp_bytes ? c->scan_tmp_bytes : 16));
             c->cum_alloc = ncum;
         }
-        if (nslot > c->mirror_alloc) {
-            hipFree(c->mirror); hipFree(c->mirror_idx);
-            c->mirror = nullptr; c->mirror_idx = nullptr; c->mirror_alloc = 0;
-            TC_HIP(c, hipMalloc(&c->mirror, (nslot + 1) * sizeof(float4)));
-            TC_HIP(c, hipMalloc(&c->mirror_idx, (nslot + 1) * sizeof(uint32_t)));
-            c->mirror_alloc = nslot;
-            /* one extra slot infinitely far away: padding lanes of a candidate batch load it and fail every
-             * distance test by themselves (no per-lane "active" flag in the predicate) */
-            const float inf = HUGE_VALF;
-            const float4 far = make_float4(inf, inf, inf, 0.0f);
-            const uint32_t none = 0xffffffffu;
-            TC_HIP(c, hipMemcpy(c->mirror + nslot, &far, sizeof(far), hipMemcpyHostToDevice));
-            TC_HIP(c, hipMemcpy(c->mirror_idx + nslot, &none, sizeof(none), hipMemcpyHostToDevice));
-        }
+        (void)nslot;         /* the mirror itself is allocated by the pass that builds it, for its local set (tc_launch_mirror) */
     }
     return 0;
 }
@@ -1111,6 +1096,7 @@ static int density_stats(tcgpu_ctx *c)
     uint32_t *h = (uint32_t *)malloc(4 * cap * sizeof(uint32_t));
     uint32_t *own = (uint32_t *)malloc((nown ? nown : 1) * sizeof(uint32_t));
     if (!h || !own) { free(h); free(own); return TCGPU_ERR_NOMEM; }
+    if (!c->stats) { free(h); free(own); TC_FAIL(c, TCGPU_ERR_ARG, "no work counters: option stats was off during the pass"); }
     hipError_t e = hipMemcpy(h, c->stats, 4 * cap * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess && c->nranks > 1) e = hipMemcpy(own, c->own_list, nown * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
@@ -1163,7 +1149,7 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
         int ride = !with_wvt ? 0 : c->sweep_mode == 1 ? 1 : (c->sweep_mode == 0 && !c->xsweep_kernel) ? 2 : 0;
         /* per-particle lists: not when they would not fit, and not for the few full-set passes of a sharded context (cold
          * start, repeated pass) -- sized for everything they would be R times what the rank needs afterwards */
-        if (ride == 2 && multi(c) && c->local_full) ride = 0;
+        if (ride == 2 && multi(c) && (c->local_full || c->margin_widen > 0)) ride = 0;    /* (a repeated pass has a wider shell) */
         if (ride == 2) { c->lists_unfit = !xlists_fit(c); if (c->lists_unfit) ride = 0; }
         /* nor on a cold pass: without a carried hsml no particle gets a list, and the wave-per-particle kernel that serves
          * the unlisted few would serve everybody (41 ms at 2e6 against 8 ms for the stand-alone sweep) */
@@ -1171,6 +1157,13 @@ static int density_pass_launch(tcgpu_ctx *c, int need_guess, int with_wvt, int f
         if (ride == 2 && tc_ensure_xlists(c)) { ride = 0; c->lists_unfit = 1; }       /* memory not to be had: no lists this pass */
         if (ride == 2) {                                                            /* the ordered runs come from pf; */
             if (!c->pf_valid && (rc = tc_launch_pfirst(c))) return rc;              /* nobody needs the mirror */
+            if (multi(c) && c->mirror) {
+                /* a sharded rank in steady state: the mirror of the full-set passes (cold start, presentation) is
+                 * 20 B x 5 levels x N that nobody reads any more -- given back; a later mirror pass allocates for ITS set */
+                TC_HIP(c, hipStreamSynchronize(c->stream));
+                TC_FREE(c->mirror); TC_FREE(c->mirror_idx);
+                c->mirror_alloc = 0; c->mirror_valid = 0;
+            }
         } else if ((rc = tc_launch_mirror(c))) return rc;
         if ((rc = tc_launch_iter(c, ride))) return rc;
         c->ustep_valid = ride == 1;

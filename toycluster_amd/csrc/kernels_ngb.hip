@@ -1200,6 +1200,7 @@ int tc_launch_density(tcgpu_ctx *c)
     a.bias_const = -0.0116 * pow(TC_DESNNGB * 0.01, -2.236);   /* src/sph.c:206 */
     a.spill = c->spill;
     a.flags = c->flags;
+    if (c->want_stats && !c->stats) TC_HIP(c, hipMalloc(&c->stats, 4 * (size_t)c->cap * sizeof(uint32_t)));      /* on first use */
     a.stats = c->want_stats ? c->stats : nullptr;
     a.stats_stride = (int)c->cap;
     int nloc = a.k.hi - a.k.lo;
@@ -2936,8 +2937,10 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     a.d.bias_const = -0.0116 * pow(TC_DESNNGB * 0.01, -2.236);   /* src/sph.c:206 */
     a.d.spill = c->spill;
     a.d.flags = c->flags;
+    if (c->want_stats && !c->stats) TC_HIP(c, hipMalloc(&c->stats, 4 * (size_t)c->cap * sizeof(uint32_t)));      /* on first use */
     a.d.stats = c->want_stats ? c->stats : nullptr;
     a.d.stats_stride = (int)c->cap;
+    if (with_wvt == 1 && !c->ustep) TC_HIP(c, hipMalloc(&c->ustep, 3 * (size_t)c->cap * sizeof(double)));          /* option sweep = 1 only */
     a.ustep = with_wvt == 1 ? c->ustep : nullptr;
     a.xr = nullptr; a.xrn = nullptr; a.xlist = nullptr; a.xlcnt = nullptr; a.xun = nullptr; a.xun_cnt = nullptr;
     int nloc = a.d.k.hi - a.d.k.lo;

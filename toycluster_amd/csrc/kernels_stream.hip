@@ -1125,6 +1125,26 @@ int tc_launch_mirror(tcgpu_ctx *c)
     c->mirror_valid = 0;
     if (!c->rows || c->lmax_rm <= 0 || !c->index_valid) return 0;
     const int n = (int)c->nloc;
+    {   /* slots: one per particle of THIS pass's local set and mirrored level (with head room; at most the capacity) */
+        size_t per = (size_t)c->nloc + (size_t)c->nloc / 8 + 1024;
+        if (per > (size_t)c->cap) per = (size_t)c->cap;
+        const size_t need = (size_t)(c->lmax_rm - c->lmin_rm + 1) * (size_t)c->nloc;
+        if (need > c->mirror_alloc) {
+            const size_t nslot = (size_t)(c->lmax_rm0 - c->lmin_rm0 + 1) * per;
+            hipFree(c->mirror); hipFree(c->mirror_idx);
+            c->mirror = nullptr; c->mirror_idx = nullptr; c->mirror_alloc = 0;
+            TC_HIP(c, hipMalloc(&c->mirror, (nslot + 1) * sizeof(float4)));
+            TC_HIP(c, hipMalloc(&c->mirror_idx, (nslot + 1) * sizeof(uint32_t)));
+            c->mirror_alloc = nslot;
+            /* one extra slot infinitely far away: padding lanes of a candidate batch load it and fail every
+             * distance test by themselves (no per-lane "active" flag in the predicate) */
+            const float inf = HUGE_VALF;
+            const float4 far = make_float4(inf, inf, inf, 0.0f);
+            const uint32_t none = 0xffffffffu;
+            TC_HIP(c, hipMemcpy(c->mirror + nslot, &far, sizeof(far), hipMemcpyHostToDevice));
+            TC_HIP(c, hipMemcpy(c->mirror_idx + nslot, &none, sizeof(none), hipMemcpyHostToDevice));
+        }
+    }
     /* scan only the mirrored levels (contiguous in the table); `cum` is addressed with table offsets through a pointer
      * shifted back by the offset of the first mirrored level (tc_cum_base) */
     const size_t first = c->h_lvl[c->lmin_rm].off;
