@@ -146,6 +146,15 @@ def loopback_group(contexts):
         c.rank, c.nranks = r, len(contexts)
 
 
+def device_memory_used():
+    """Bytes in use on the current device (hipMemGetInfo: total - free) -- for tests and probes of what the contexts hold."""
+    hip = C.CDLL("libamdhip64.so")
+    fr, tot = C.c_size_t(), C.c_size_t()
+    if hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) != 0:
+        raise TcGpuError("hipMemGetInfo failed")
+    return tot.value - fr.value
+
+
 class TcGpu:
     """One context per GPU (the reference's globals, made explicit)."""
 
