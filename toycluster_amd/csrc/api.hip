@@ -1502,6 +1502,16 @@ extern "C" int tcgpu_debug_xlist_stats(tcgpu_ctx *c, double *out)
     return TCGPU_OK;
 }
 
+/* profiling: the neighbour-list lengths of the last list pass, one per local slot (TC_XNONE: not listed) */
+extern "C" int tcgpu_debug_xlcnt(tcgpu_ctx *c, uint32_t *out, int64_t n)
+{
+    if (!c || !out || !c->xlcnt || !c->xlist_valid || n > c->nloc) return TCGPU_ERR_ARG;
+    TC_HIP(c, hipSetDevice(c->device));
+    TC_HIP(c, hipStreamSynchronize(c->stream));
+    TC_HIP(c, hipMemcpy(out, c->xlcnt, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return TCGPU_OK;
+}
+
 /* ------------------------------------------------------------------ options / timing */
 
 extern "C" int tcgpu_set_option(tcgpu_ctx *c, const char *name, double value)
