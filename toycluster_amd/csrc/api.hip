@@ -171,7 +171,7 @@ static void free_particles(tcgpu_ctx *c)
     TC_FREE(c->apot); TC_FREE(c->bfld); TC_FREE(c->l_apot);
     TC_FREE(c->key); TC_FREE(c->key_sorted); TC_FREE(c->idx); TC_FREE(c->idx_sorted); TC_FREE(c->sort_tmp);
     TC_FREE(c->cells); TC_FREE(c->guess); TC_FREE(c->hwvt); TC_FREE(c->delta); TC_FREE(c->stats); TC_FREE(c->ngb_buf);
-    TC_FREE(c->ustep); TC_FREE(c->rhom_next); TC_FREE(c->prec); TC_FREE(c->xruns); c->xruns_bytes = 0;
+    TC_FREE(c->ustep); TC_FREE(c->rhom_next); TC_FREE(c->prec); c->prec_cap = 0; TC_FREE(c->xruns); c->xruns_bytes = 0;
     TC_FREE(c->xr); TC_FREE(c->xrn); TC_FREE(c->xlist); TC_FREE(c->xlcnt); TC_FREE(c->xun); c->xr_cap = 0; c->xlist_valid = 0;
     TC_FREE(c->cum); TC_FREE(c->scan_tmp); TC_FREE(c->mirror); TC_FREE(c->mirror_idx);
     TC_FREE(c->pf); TC_FREE(c->pf_tmp); c->pf_alloc = 0; c->pf_valid = 0;

@@ -2897,6 +2897,20 @@ __global__ __launch_bounds__(TBN) void k_xruns(tc_dev_const k, const tc_prec *__
     });
 }
 
+/* the 64-byte query records (tc_prec / tc_cprec share the slots): one per LOCAL slot of the pass, with head room; a sharded
+ * rank that has shrunk from a full-set pass to its steady-state local set gives the difference back */
+int tc_ensure_prec(tcgpu_ctx *c)
+{
+    static_assert(sizeof(tc_prec) == 64, "64-byte record slots");
+    size_t want = (size_t)c->nloc + (size_t)c->nloc / 8 + 1024;
+    if (want > (size_t)c->cap) want = (size_t)c->cap;
+    if (c->prec && c->prec_cap >= (size_t)c->nloc && !(c->nranks > 1 && c->prec_cap > 2 * want)) return 0;
+    if (c->prec) { TC_HIP(c, hipStreamSynchronize(c->stream)); hipFree(c->prec); c->prec = nullptr; c->prec_cap = 0; }
+    TC_HIP(c, hipMalloc(&c->prec, want * sizeof(tc_prec)));
+    c->prec_cap = want;
+    return 0;
+}
+
 /* run lists and neighbour lists of every local slot (own particles use theirs), sized by the local set of this pass (with
  * head room), not by the particle capacity: on a sharded rank the local set is a fraction of everything, and the lists are
  * what takes the memory (xlists_fit, api.hip).  Returns non-zero when the memory is not to be had: the caller then runs
@@ -2945,7 +2959,7 @@ int tc_launch_iter(tcgpu_ctx *c, int with_wvt)
     a.xr = nullptr; a.xrn = nullptr; a.xlist = nullptr; a.xlcnt = nullptr; a.xun = nullptr; a.xun_cnt = nullptr;
     int nloc = a.d.k.hi - a.d.k.lo;
     if (nloc <= 0) return 0;
-    if (!c->prec) TC_HIP(c, hipMalloc(&c->prec, (size_t)c->cap * sizeof(tc_prec)));
+    { int rp = tc_ensure_prec(c); if (rp) return rp; }
     a.prec = (const tc_prec *)c->prec;
     tc_phase_begin(c, PH_PREC);
     k_prec<<<(nloc + 255) / 256, 256, 0, c->stream>>>(a.d.k, a.d.hsml_in, with_wvt != 0, c->no_records, (tc_prec *)c->prec);
@@ -3321,7 +3335,7 @@ int tc_launch_curl(tcgpu_ctx *c, float *l_bfld, int a_in_w)
     a.flags = c->flags;
     int nloc = a.k.hi - a.k.lo;
     if (nloc <= 0) return 0;
-    if (!c->prec) TC_HIP(c, hipMalloc(&c->prec, (size_t)c->cap * sizeof(tc_cprec)));
+    { int rp = tc_ensure_prec(c); if (rp) return rp; }
     a.prec = (const tc_cprec *)c->prec;
     tc_phase_begin(c, PH_CURL);
     TC_HIP(c, hipMemsetAsync(c->work_ctr, 0, 8 * 16 * sizeof(int), c->stream));

@@ -207,7 +207,8 @@ struct tcgpu_ctx {
     double *spill;                /* TC_MAX_PERSISTENT_BLOCKS*WPB x 2*NGBMAX */
     double *ustep;                /* 3*cap: unit-step WVT displacement sums of the fused kernel (local order) */
     int no_records;               /* option "no_records" (tests): mark every per-particle record unusable */
-    void *prec;                   /* cap x 64 B: per-particle query records of the fused kernel (k_prec), on demand */
+    void *prec;                   /* 64 B per local slot: per-particle query records of the fused kernel (k_prec) / the curl, on demand */
+    size_t prec_cap;              /* ... slots allocated (sized by the local set of the pass that needs them) */
     float *rhom_next;             /* cap: model density at the current positions, committed by the sweep (G order) */
     int ustep_valid;              /* ustep belongs to the current local order and positions */
     int fuse;                     /* option: use the fused kernel (default 1) */
@@ -427,6 +428,7 @@ int tc_launch_scatter_bfld(tcgpu_ctx *c, const float *l_bfld);
 /* neighbour kernels */
 int tc_launch_density(tcgpu_ctx *c);
 int tc_launch_iter(tcgpu_ctx *c, int with_wvt);   /* fused density (+ unit-step WVT sums) */
+int tc_ensure_prec(tcgpu_ctx *c);                 /* query records for this pass's local set */
 int tc_ensure_xlists(tcgpu_ctx *c);               /* per-particle lists of the ordered gather for this pass's local set; != 0: no memory */
 int tc_launch_apply_step(tcgpu_ctx *c, double step);  /* delta (G order) = step * ustep (local order) */
 int tc_launch_wvt(tcgpu_ctx *c, double step);
